@@ -1,0 +1,98 @@
+"""ctypes binding of libc2mi.so (the C-ABI declared in include/c2mi.h).
+
+The library is the product: if it cannot be loaded the import fails loudly --
+there is no CPU or eager-PyTorch fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libc2mi.so")
+
+F32, BF16 = 0, 1
+MMD_MAX_PARTS = 64
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C celligner2_amd/csrc` (or __graft_entry__.build()); "
+        "celligner2_amd has no fallback path"
+    )
+lib = C.CDLL(LIB_PATH)
+
+i64, i32, f32, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64)]
+
+
+_SIGS = {
+    "c2_last_error": (C.c_char_p, []),
+    "c2_version": (i32, []),
+    "c2_prep_input": (i32, [vp, i64, i64, i64, vp, i32, i64, i32, vp]),
+    "c2_linear_fwd": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_dgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
+    "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp]),
+    "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp]),
+    "c2_bias_cond_grad_ws": (sz, [i64, i64, i32]),
+    "c2_bias_cond_grad": (i32, [vp, i32, i64, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp]),
+    "c2_reduce_ws": (sz, []),
+    "c2_reparam_kl_fwd": (i32, [vp, vp, vp, i64, i64, i64, f32, i32, vp, vp, i32, i64, vp, vp, vp]),
+    "c2_reparam_kl_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, vp, vp, i64, i64, i64, f32, i32, vp, vp, vp, i32, i64, vp]),
+    "c2_recon_nb_ws": (sz, [i64, i64, i32]),
+    "c2_recon_nb_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, i32, i64, vp, vp, vp, vp]),
+    "c2_recon_mse_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, f32, vp, vp, i32, i64, vp, vp]),
+    "c2_classifier_loss_fwd_bwd": (i32, [vp, i64, vp, i64, i32, f32, vp, vp, i32, i64, vp, vp]),
+    "c2_partition_ws": (sz, [i64]),
+    "c2_partition": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "c2_mmd_ws": (sz, [i64, i64, i64]),
+    "c2_mmd_fwd_bwd": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp, vp]),
+    "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, f32, i64, vp]),
+    "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "c2_axpy": (i32, [vp, vp, vp, i64, vp]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = sorted(_SIGS)
+
+
+class C2Error(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise C2Error(lib.c2_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise C2Error("celligner2_amd kernels need tensors on an MI355X device (no CPU fallback)")

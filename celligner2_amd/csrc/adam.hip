@@ -1,0 +1,110 @@
+// Fused multi-tensor Adam (torch.optim.Adam semantics as celligner2/trainers/celligner2/trainer.py:262-266,316-323
+// sets it up: L2 weight decay folded into the gradient, optional clip_grad_value_, bias correction) for gfx950.
+// One launch updates up to kMaxT tensors: 28 B/param of HBM traffic (+2 B when a bf16 shadow copy of the
+// weights is refreshed for the bf16-operand GEMMs), 16-byte accesses, no atomics.
+#include "common.h"
+
+namespace c2 {
+
+constexpr int kMaxT = 48;
+constexpr int kElemsPerBlock = 256 * 8;
+
+struct AdamTable {
+    c2_adam_tensor t[kMaxT];
+    int first_block[kMaxT + 1];
+    int n;
+};
+
+struct AdamHyper {
+    float step_size, beta1, beta2, omb1, omb2, eps, wd, clip, inv_bc2_sqrt;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamHyper& h) {
+    if (h.clip > 0.f) g = fminf(fmaxf(g, -h.clip), h.clip);
+    g = g + h.wd * p;
+    m = h.beta1 * m + h.omb1 * g;
+    v = h.beta2 * v + h.omb2 * g * g;
+    const float denom = sqrtf(v) * h.inv_bc2_sqrt + h.eps;
+    p = p - h.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
+    // locate the tensor of this block (tab.n <= 48: linear scan on scalar registers)
+    int ti = 0;
+    while (ti + 1 < tab.n && (int)blockIdx.x >= tab.first_block[ti + 1]) ++ti;
+    const c2_adam_tensor t = tab.t[ti];
+    const int64_t base = (int64_t)(blockIdx.x - tab.first_block[ti]) * kElemsPerBlock;
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
+                       reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0 &&
+                     (!t.shadow_bf16 || (reinterpret_cast<uintptr_t>(t.shadow_bf16) & 7) == 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
+        if (i >= t.n) continue;
+        if (vec && i + 4 <= t.n) {
+            f32x4 p = *reinterpret_cast<f32x4*>(t.p + i);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
+            f32x4 m = *reinterpret_cast<f32x4*>(t.m + i);
+            f32x4 v = *reinterpret_cast<f32x4*>(t.v + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = p[e], me = m[e], ve = v[e];
+                adam_one(pe, g[e], me, ve, h);
+                p[e] = pe; m[e] = me; v[e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(t.p + i) = p;
+            *reinterpret_cast<f32x4*>(t.m + i) = m;
+            *reinterpret_cast<f32x4*>(t.v + i) = v;
+            if (t.shadow_bf16) {
+                u32x2 pk;
+                pk[0] = (unsigned)f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
+                pk[1] = (unsigned)f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
+            }
+        } else {
+            for (int e = 0; e < 4 && i + e < t.n; ++e) {
+                float pe = t.p[i + e], me = t.m[i + e], ve = t.v[i + e];
+                adam_one(pe, t.g[i + e], me, ve, h);
+                t.p[i + e] = pe; t.m[i + e] = me; t.v[i + e] = ve;
+                if (t.shadow_bf16) reinterpret_cast<bf16_t*>(t.shadow_bf16)[i + e] = f2bf(pe);
+            }
+        }
+    }
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, float clip_value, int64_t step_t, void* stream) {
+    C2_CHECK(desc_host || n_tensors == 0, "null descriptor table");
+    C2_CHECK(step_t >= 1, "step_t must be >= 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step_t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step_t);
+    AdamHyper h;
+    h.step_size = (float)((double)lr / bc1);
+    h.beta1 = beta1; h.beta2 = beta2;
+    h.omb1 = (float)(1.0 - (double)beta1); h.omb2 = (float)(1.0 - (double)beta2);  // as torch: 1-beta in double
+    h.eps = eps; h.wd = weight_decay; h.clip = clip_value;
+    h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    for (int s = 0; s < n_tensors; s += kMaxT) {
+        AdamTable tab;
+        tab.n = 0;
+        int blocks = 0;
+        for (int i = s; i < n_tensors && tab.n < kMaxT; ++i) {
+            const c2_adam_tensor& d = desc_host[i];
+            if (d.n == 0) continue;
+            C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");
+            tab.t[tab.n] = d;
+            tab.first_block[tab.n] = blocks;
+            blocks += (int)((d.n + kElemsPerBlock - 1) / kElemsPerBlock);
+            ++tab.n;
+        }
+        tab.first_block[tab.n] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, h);
+    }
+    C2_LAUNCH_CHECK();
+    return 0;
+}

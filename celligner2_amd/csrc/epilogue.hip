@@ -1,0 +1,577 @@
+// HBM-bound row kernels around the GEMMs: input transform, layer tail (bias + condition columns +
+// LayerNorm + ReLU + dropout) forward/backward, bias/condition-weight gradients, reparameterisation + KL,
+// dataset row gather and small vector helpers.  One 64-lane wave owns one row: every row statistic is a
+// wavefront-shuffle reduction, no LDS, no atomics (bit-stable results).
+#include "common.h"
+
+#include <mutex>
+
+namespace c2 {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+__global__ void finalize_sum_kernel(const float* __restrict__ partials, int n, float* __restrict__ out) {
+    __shared__ float red[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) *out += s;
+}
+int launch_finalize_sum(const float* partials, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, stream, partials, n, out);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TO, bool VEC4>
+__global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ldx,
+                                  TO* __restrict__ out, int64_t ldo, int apply_log) {
+    if (VEC4) {
+        const int64_t cv = cols >> 2;
+        const int64_t total = rows * cv;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / cv, c = (i - r * cv) << 2;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+            if (apply_log) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = logf(1.0f + v[e]);
+            }
+            TO* o = out + r * ldo + c;
+            if (sizeof(TO) == 4) {
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+                u32x2 pk;
+                pk[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(o) = pk;
+            }
+        }
+    } else {
+        const int64_t total = rows * cols;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / cols, c = i - r * cols;
+            float v = x[r * ldx + c];
+            if (apply_log) v = logf(1.0f + v);
+            st_from_f32<TO>(out + r * ldo + c, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer tail forward: wave per row
+template <typename TO, int EPL /*cached float4 chunks per lane, 0 = no cache*/>
+__global__ __launch_bounds__(256) void epilogue_fwd_kernel(
+    const float* __restrict__ Y, int64_t ldy, int nslab, int64_t slab_stride, const float* __restrict__ bias,
+    const int64_t* __restrict__ cond, int C, const float* __restrict__ Wc, int64_t ldwc,
+    const uint8_t* __restrict__ mask, float keep_scale, int use_ln, int64_t B, int H, TO* __restrict__ act,
+    int64_t ldact, float* __restrict__ yhat, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int64_t* crow = cond ? cond + row * C : nullptr;
+
+    auto hval = [&](int c) -> float {
+        float h = 0.f;
+        for (int s = 0; s < nslab; ++s) h += Y[s * slab_stride + row * ldy + c];
+        if (bias) h += bias[c];
+        if (crow) {
+            for (int j = 0; j < C; ++j) {
+                const float cj = (float)crow[j];
+                if (cj != 0.f) h += cj * Wc[(int64_t)c * ldwc + j];
+            }
+        }
+        return h;
+    };
+
+    float cache[EPL > 0 ? EPL * 4 : 1];
+    float sum = 0.f;
+    if (EPL > 0) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * i) * 4 + e;
+                const float h = (c < H) ? hval(c) : 0.f;
+                cache[i * 4 + e] = h;
+                sum += h;
+            }
+        }
+    } else {
+        for (int c = lane; c < H; c += 64) sum += hval(c);
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (use_ln) {
+        mean = wave_sum(sum) / (float)H;
+        float vs = 0.f;
+        if (EPL > 0) {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (lane + 64 * i) * 4 + e;
+                    const float d = cache[i * 4 + e] - mean;
+                    vs += (c < H) ? d * d : 0.f;
+                }
+        } else {
+            for (int c = lane; c < H; c += 64) {
+                const float d = hval(c) - mean;
+                vs += d * d;
+            }
+        }
+        const float var = wave_sum(vs) / (float)H;
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+    }
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+
+    auto emit = [&](int c, float h) {
+        const float yh = (h - mean) * rstd;
+        if (yhat) yhat[row * (int64_t)H + c] = yh;
+        float r = fmaxf(yh, 0.f);
+        if (mask) r = mask[row * (int64_t)H + c] ? r * keep_scale : 0.f;
+        st_from_f32<TO>(act + row * ldact + c, r);
+    };
+    if (EPL > 0) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * i) * 4 + e;
+                if (c < H) emit(c, cache[i * 4 + e]);
+            }
+    } else {
+        for (int c = lane; c < H; c += 64) emit(c, hval(c));
+    }
+}
+
+// layer tail backward: wave per row
+template <typename TO, int EPL>
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(
+    const float* __restrict__ dA, int64_t ldda, int nslab, int64_t slab_stride, const float* __restrict__ extra,
+    int64_t ldextra, const float* __restrict__ extra_scale_dev, const uint8_t* __restrict__ mask, float keep_scale,
+    int use_ln, const float* __restrict__ yhat, const float* __restrict__ rstd_in, int64_t B, int H,
+    TO* __restrict__ dh, int64_t lddh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float es = (extra && extra_scale_dev) ? *extra_scale_dev : 1.f;
+
+    auto dyval = [&](int c, float& yh) -> float {
+        float d = 0.f;
+        for (int s = 0; s < nslab; ++s) d += dA[s * slab_stride + row * ldda + c];
+        if (extra) d += es * extra[row * ldextra + c];
+        if (mask) d = mask[row * (int64_t)H + c] ? d * keep_scale : 0.f;
+        yh = yhat[row * (int64_t)H + c];
+        return yh > 0.f ? d : 0.f;
+    };
+    float cdy[EPL > 0 ? EPL * 4 : 1], cyh[EPL > 0 ? EPL * 4 : 1];
+    float s1 = 0.f, s2 = 0.f;
+    if (EPL > 0) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * i) * 4 + e;
+                float yh = 0.f;
+                const float d = (c < H) ? dyval(c, yh) : 0.f;
+                cdy[i * 4 + e] = d;
+                cyh[i * 4 + e] = yh;
+                s1 += d;
+                s2 += d * yh;
+            }
+    } else {
+        for (int c = lane; c < H; c += 64) {
+            float yh;
+            const float d = dyval(c, yh);
+            s1 += d;
+            s2 += d * yh;
+        }
+    }
+    float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+    if (use_ln) {
+        m1 = wave_sum(s1) / (float)H;
+        m2 = wave_sum(s2) / (float)H;
+        rstd = rstd_in[row];
+    }
+    if (EPL > 0) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (lane + 64 * i) * 4 + e;
+                if (c < H) {
+                    const float g = use_ln ? (cdy[i * 4 + e] - m1 - cyh[i * 4 + e] * m2) * rstd : cdy[i * 4 + e];
+                    st_from_f32<TO>(dh + row * lddh + c, g);
+                }
+            }
+    } else {
+        for (int c = lane; c < H; c += 64) {
+            float yh;
+            const float d = dyval(c, yh);
+            const float g = use_ln ? (d - m1 - yh * m2) * rstd : d;
+            st_from_f32<TO>(dh + row * lddh + c, g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// db / dWc: stage 1 -- block = 256 columns x RB rows; stage 2 -- sum over row chunks.
+constexpr int kBCG_RB = 64;
+template <typename TI>
+__global__ __launch_bounds__(256) void bias_cond_stage1(const TI* __restrict__ dh, int64_t lddh,
+                                                        const int64_t* __restrict__ cond, int C, int64_t B, int H,
+                                                        float* __restrict__ ws /*[nchunk][1+C][H]*/) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int64_t b0 = (int64_t)chunk * kBCG_RB, b1 = min(B, b0 + kBCG_RB);
+    float* out = ws + (int64_t)chunk * (1 + C) * H;
+    if (col >= H) return;
+    float a0 = 0.f;
+    for (int64_t b = b0; b < b1; ++b) a0 += ld_as_f32<TI>(dh + b * lddh + col);
+    out[col] = a0;
+    for (int j0 = 0; j0 < C; j0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t b = b0; b < b1; ++b) {
+            const float v = ld_as_f32<TI>(dh + b * lddh + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < C) acc[j] += v * (float)cond[b * C + j0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j0 + j < C) out[(int64_t)(1 + j0 + j) * H + col] = acc[j];
+    }
+}
+__global__ void bias_cond_stage2(const float* __restrict__ ws, int nchunk, int C, int H, float* __restrict__ db,
+                                 float* __restrict__ dWc, int64_t lddwc, const float* __restrict__ alpha_dev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (1+C)*H
+    if (i >= (1 + C) * H) return;
+    const int k = i / H, col = i - k * H;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += ws[(int64_t)c * (1 + C) * H + i];
+    const float alpha = alpha_dev ? *alpha_dev : 1.f;
+    s *= alpha;
+    if (k == 0) {
+        if (db) db[col] = s;
+    } else if (dWc) {
+        dWc[(int64_t)col * lddwc + (k - 1)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TZ>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                             const float* __restrict__ eps, int64_t B, int L,
+                                                             int64_t ld, float inv_B, int use_own_kl,
+                                                             float* __restrict__ z32, TZ* __restrict__ zt,
+                                                             int64_t ldzt, float* __restrict__ partials) {
+    __shared__ float red[32];
+    const int64_t total = B * L;
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / L;
+        const int l = (int)(i - b * L);
+        const float m = mu[b * ld + l], v_l = lv[b * ld + l];
+        const float var = expf(v_l) + 1e-4f;
+        const float z = m + sqrtf(var) * eps[b * (int64_t)L + l];
+        z32[b * (int64_t)L + l] = z;
+        if (zt) st_from_f32<TZ>(zt + b * ldzt + l, z);
+        if (use_own_kl)
+            acc += -0.5f * (1.f + v_l - m * m - var);
+        else
+            acc += 0.5f * (var + m * m - 1.f - logf(var)) * inv_B;
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+template <typename TO>
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ dZ, int64_t lddz, int nslab, int64_t slab_stride,
+                                      const float* __restrict__ extra, int64_t ldextra,
+                                      const float* __restrict__ extra_scale_dev, const float* __restrict__ mu,
+                                      const float* __restrict__ lv, const float* __restrict__ eps, int64_t B, int L,
+                                      int64_t ld, float inv_B, int use_own_kl, const float* __restrict__ g_kl_dev,
+                                      TO* __restrict__ dmu, TO* __restrict__ dlv, int64_t ldout) {
+    const int64_t total = B * L;
+    const float gk = g_kl_dev ? *g_kl_dev : 1.f;
+    const float es = (extra && extra_scale_dev) ? *extra_scale_dev : 1.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / L;
+        const int l = (int)(i - b * L);
+        float dz = 0.f;
+        for (int s = 0; s < nslab; ++s) dz += dZ[s * slab_stride + b * lddz + l];
+        if (extra) dz += es * extra[b * ldextra + l];
+        const float m = mu[b * ld + l], v_l = lv[b * ld + l];
+        const float ex = expf(v_l);
+        const float var = ex + 1e-4f;
+        float dm_kl, dl_kl;
+        if (use_own_kl) {
+            dm_kl = m;
+            dl_kl = -0.5f * (1.f - ex);
+        } else {
+            dm_kl = m * inv_B;
+            dl_kl = 0.5f * (1.f - 1.f / var) * ex * inv_B;
+        }
+        const float gm = dz + gk * dm_kl;
+        const float gl = dz * eps[b * (int64_t)L + l] * ex / (2.f * sqrtf(var)) + gk * dl_kl;
+        st_from_f32<TO>(dmu + b * ldout + l, gm);
+        st_from_f32<TO>(dlv + b * ldout + l, gl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ goodloc, const float* __restrict__ sizefactor,
+    const int64_t* __restrict__ cond, const int64_t* __restrict__ classes, int64_t G, int C, int P,
+    const int64_t* __restrict__ idx, float* __restrict__ x_out, uint8_t* __restrict__ goodloc_out,
+    float* __restrict__ sf_out, int64_t* __restrict__ cond_out, int64_t* __restrict__ classes_out,
+    TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok) {
+    const int64_t r = blockIdx.x;
+    const int64_t src = idx[r];
+    const float* xs = X + src * G;
+    float* xd = x_out + r * G;
+    if (vec_ok) {
+        const int64_t gv = G >> 2;
+        for (int64_t c = threadIdx.x; c < gv; c += 256) {
+            f32x4 v = reinterpret_cast<const f32x4*>(xs)[c];
+            reinterpret_cast<f32x4*>(xd)[c] = v;
+            if (xin_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = apply_log ? logf(1.0f + v[e]) : v[e];
+                    st_from_f32<TX>(xin_out + r * ldxin + c * 4 + e, t);
+                }
+            }
+            if (goodloc)
+                reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] =
+                    reinterpret_cast<const unsigned int*>(goodloc + src * G)[c];
+        }
+    } else {
+        for (int64_t c = threadIdx.x; c < G; c += 256) {
+            const float v = xs[c];
+            xd[c] = v;
+            if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, apply_log ? logf(1.0f + v) : v);
+            if (goodloc) goodloc_out[r * G + c] = goodloc[src * G + c];
+        }
+    }
+    if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
+    if (cond)
+        for (int j = threadIdx.x; j < C; j += 256) cond_out[r * C + j] = cond[src * C + j];
+    if (classes)
+        for (int j = threadIdx.x; j < P; j += 256) classes_out[r * P + j] = classes[src * P + j];
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, const float* __restrict__ a_dev, float* __restrict__ y,
+                            int64_t n) {
+    const float a = a_dev ? *a_dev : 1.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+__global__ void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = f2bf(s[i]);
+}
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, cap));
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+extern "C" const char* c2_last_error(void) { return g_err.c_str(); }
+extern "C" int c2_version(void) { return 1; }
+extern "C" size_t c2_reduce_ws(void) { return kReduceWsFloats; }
+
+extern "C" int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* out, int out_dtype,
+                             int64_t ldo, int apply_log, void* stream) {
+    C2_CHECK(x && out, "null pointer");
+    C2_CHECK(out_dtype == C2_F32 || out_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(ldx >= cols && ldo >= cols && rows >= 0 && cols >= 0, "bad shape");
+    if (rows == 0 || cols == 0) return 0;
+    const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+    const int grid = grid_for(rows * cols / (vec ? 4 : 1));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(TO, V) \
+    hipLaunchKernelGGL((prep_input_kernel<TO, V>), dim3(grid), dim3(256), 0, st, x, rows, cols, ldx, (TO*)out, ldo, apply_log)
+    if (out_dtype == C2_F32) {
+        if (vec) LAUNCH(float, true); else LAUNCH(float, false);
+    } else {
+        if (vec) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false);
+    }
+#undef LAUNCH
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
+                               const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
+                               float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype,
+                               int64_t ldact, float* yhat, float* rstd, void* stream) {
+    C2_CHECK(Y && act, "null pointer");
+    C2_CHECK(act_dtype == C2_F32 || act_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(nslab >= 1 && ldy >= H && ldact >= H && H < (1ll << 31), "bad shape");
+    C2_CHECK(!(cond && C > 0) || Wc, "cond given without Wc");
+    C2_CHECK(p_drop >= 0.f && p_drop < 1.f, "bad dropout rate");
+    if (B == 0 || H == 0) return 0;
+    if (C == 0) cond = nullptr;
+    const float ks = 1.0f / (1.0f - p_drop);
+    dim3 grid((unsigned)((B + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(TO, E)                                                                                              \
+    hipLaunchKernelGGL((epilogue_fwd_kernel<TO, E>), grid, dim3(256), 0, st, Y, ldy, nslab, slab_stride, bias, cond, \
+                       C, Wc, ldwc, mask, ks, use_ln, B, (int)H, (TO*)act, ldact, yhat, rstd)
+    if (act_dtype == C2_F32) {
+        if (H <= 256) LAUNCH(float, 1); else if (H <= 1024) LAUNCH(float, 4); else LAUNCH(float, 0);
+    } else {
+        if (H <= 256) LAUNCH(bf16_t, 1); else if (H <= 1024) LAUNCH(bf16_t, 4); else LAUNCH(bf16_t, 0);
+    }
+#undef LAUNCH
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
+                               int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
+                               int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
+                               int dh_dtype, int64_t lddh, void* stream) {
+    C2_CHECK(dA && yhat && dh, "null pointer");
+    C2_CHECK(!use_ln || rstd, "rstd needed with use_ln");
+    C2_CHECK(dh_dtype == C2_F32 || dh_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(nslab >= 1 && ldda >= H && lddh >= H && H < (1ll << 31), "bad shape");
+    C2_CHECK(p_drop >= 0.f && p_drop < 1.f, "bad dropout rate");
+    if (B == 0 || H == 0) return 0;
+    const float ks = 1.0f / (1.0f - p_drop);
+    dim3 grid((unsigned)((B + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(TO, E)                                                                                            \
+    hipLaunchKernelGGL((epilogue_bwd_kernel<TO, E>), grid, dim3(256), 0, st, dA, ldda, nslab, slab_stride, extra, \
+                       ldextra, extra_scale_dev, mask, ks, use_ln, yhat, rstd, B, (int)H, (TO*)dh, lddh)
+    if (dh_dtype == C2_F32) {
+        if (H <= 256) LAUNCH(float, 1); else if (H <= 1024) LAUNCH(float, 4); else LAUNCH(float, 0);
+    } else {
+        if (H <= 256) LAUNCH(bf16_t, 1); else if (H <= 1024) LAUNCH(bf16_t, 4); else LAUNCH(bf16_t, 0);
+    }
+#undef LAUNCH
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t c2_bias_cond_grad_ws(int64_t B, int64_t H, int C) {
+    const int64_t nchunk = (B + kBCG_RB - 1) / kBCG_RB;
+    return (size_t)(nchunk * (1 + C) * H);
+}
+
+extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, const int64_t* cond, int C, int64_t B,
+                                 int64_t H, float* db, float* dWc, int64_t lddwc, const float* alpha_dev, float* ws,
+                                 void* stream) {
+    C2_CHECK(dh && ws, "null pointer");
+    C2_CHECK(dh_dtype == C2_F32 || dh_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(lddh >= H && C >= 0, "bad shape");
+    C2_CHECK(!dWc || (cond && lddwc >= C), "dWc needs cond");
+    if (H == 0) return 0;
+    if (!dWc) C = 0;
+    const int nchunk = (int)std::max<int64_t>(1, (B + kBCG_RB - 1) / kBCG_RB);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g1((unsigned)((H + 255) / 256), nchunk);
+    if (dh_dtype == C2_F32)
+        hipLaunchKernelGGL((bias_cond_stage1<float>), g1, dim3(256), 0, st, (const float*)dh, lddh, cond, C, B, (int)H, ws);
+    else
+        hipLaunchKernelGGL((bias_cond_stage1<bf16_t>), g1, dim3(256), 0, st, (const bf16_t*)dh, lddh, cond, C, B, (int)H, ws);
+    const int n2 = (int)((1 + C) * H);
+    hipLaunchKernelGGL(bias_cond_stage2, dim3((n2 + 255) / 256), dim3(256), 0, st, ws, nchunk, C, (int)H, db, dWc,
+                       lddwc, alpha_dev);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_reparam_kl_fwd(const float* mu, const float* lv, const float* eps, int64_t B, int64_t L, int64_t ld,
+                                 float inv_B, int use_own_kl, float* z32, void* zt, int zt_dtype, int64_t ldzt,
+                                 float* kl_out, float* ws, void* stream) {
+    C2_CHECK(mu && lv && eps && z32 && kl_out && ws, "null pointer");
+    C2_CHECK(ld >= L && (!zt || ldzt >= L), "bad leading dimension");
+    if (B == 0 || L == 0) return 0;
+    const int grid = grid_for(B * L, 256, 1024);
+    hipStream_t st = (hipStream_t)stream;
+    if (zt && zt_dtype == C2_BF16)
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, mu, lv, eps, B, (int)L, ld,
+                           inv_B, use_own_kl, z32, (bf16_t*)zt, ldzt, ws);
+    else
+        hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, mu, lv, eps, B, (int)L, ld,
+                           inv_B, use_own_kl, z32, (float*)zt, ldzt, ws);
+    launch_finalize_sum(ws, grid, kl_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64_t slab_stride, const float* extra,
+                                 int64_t ldextra, const float* extra_scale_dev, const float* mu, const float* lv,
+                                 const float* eps, int64_t B, int64_t L, int64_t ld, float inv_B, int use_own_kl,
+                                 const float* g_kl_dev, void* dmu, void* dlv, int out_dtype, int64_t ldout,
+                                 void* stream) {
+    C2_CHECK(dZ && mu && lv && eps && dmu && dlv, "null pointer");
+    C2_CHECK(out_dtype == C2_F32 || out_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(ld >= L && ldout >= L && lddz >= L && nslab >= 1, "bad shape");
+    if (B == 0 || L == 0) return 0;
+    const int grid = grid_for(B * L);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == C2_BF16)
+        hipLaunchKernelGGL((reparam_kl_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, dZ, lddz, nslab, slab_stride,
+                           extra, ldextra, extra_scale_dev, mu, lv, eps, B, (int)L, ld, inv_B, use_own_kl, g_kl_dev,
+                           (bf16_t*)dmu, (bf16_t*)dlv, ldout);
+    else
+        hipLaunchKernelGGL((reparam_kl_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, dZ, lddz, nslab, slab_stride,
+                           extra, ldextra, extra_scale_dev, mu, lv, eps, B, (int)L, ld, inv_B, use_own_kl, g_kl_dev,
+                           (float*)dmu, (float*)dlv, ldout);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
+                              const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
+                              float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
+                              int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
+                              void* stream) {
+    C2_CHECK(X && idx && x_out, "null pointer");
+    C2_CHECK(!goodloc || goodloc_out, "goodloc_out missing");
+    C2_CHECK(!sizefactor || sf_out, "sf_out missing");
+    C2_CHECK(!cond || cond_out, "cond_out missing");
+    C2_CHECK(!classes || classes_out, "classes_out missing");
+    C2_CHECK(!xin_out || ldxin >= G, "ldxin too small");
+    if (n == 0 || G == 0) return 0;
+    const int vec_ok = (G % 4 == 0) && aligned16(X) && aligned16(x_out) &&
+                       (!goodloc || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0));
+    hipStream_t st = (hipStream_t)stream;
+    if (xin_out && xin_dtype == C2_BF16)
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+                           cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
+                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+                           cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
+                           (float*)xin_out, ldxin, apply_log, vec_ok);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, void* stream) {
+    C2_CHECK(x && y && n >= 0, "bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a_dev, y, n);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    C2_CHECK(src && dst && n >= 0, "bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    C2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,341 @@
+// MFMA GEMMs of the Linear layers (forward, dgrad, wgrad) for gfx950.
+//
+// One kernel template serves the three layouts.  C[M,N] = sum_r Aop[i][r] * Bop[j][r], where each
+// operand is either "RC" (reduction index contiguous in memory: element (x,r) at p[x*ld + r]) or
+// "XC" (output index contiguous: element (x,r) at p[r*ld + x]).  forward = (RC,RC), dgrad = (RC,XC),
+// wgrad = (XC,XC).  Tiles keep their GLOBAL orientation in LDS, so global loads and LDS writes are
+// 16-byte and coalesced for every layout; the transposition an XC operand needs is done by the LDS read:
+//   bf16: ds_read_b64_tr_b16 (gfx950 transposing read) feeds v_mfma_f32_32x32x16_bf16;
+//   fp32: v_mfma_f32_32x32x2_f32 takes one float per lane, any orientation reads conflict-free.
+// 128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32, fp32 accumulate.
+// Register-staged pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied.
+// Split reductions write fp32 slabs (deterministic; the consumer kernel sums them).
+#include "common.h"
+
+namespace c2 {
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    float* C;
+    const float* bias;
+    const float* alpha_dev;
+    int64_t lda, ldb, ldc, slab_stride;
+    int M, N, R, r_per_split;
+};
+
+template <typename T>
+struct Cfg;
+template <>
+struct Cfg<bf16_t> {
+    static constexpr int BK = 64, VEC = 8;
+    static constexpr int S_RC = 72;   // [128][72] bf16: 144-B rows, ds_read_b128 conflict-free
+    static constexpr int S_XC = 160;  // [64][160] bf16: 320-B rows, 4 k-rows hit 4 distinct 64-B bank groups
+};
+template <>
+struct Cfg<float> {
+    static constexpr int BK = 32, VEC = 4;
+    static constexpr int S_RC = 33;   // [128][33] f32
+    static constexpr int S_XC = 132;  // [32][132] f32
+};
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <typename T, bool RC>
+__host__ __device__ constexpr int tile_elems() {
+    return RC ? BM * Cfg<T>::S_RC : Cfg<T>::BK * Cfg<T>::S_XC;
+}
+
+// 16 bytes of operand data held in registers between the global load and the LDS write
+struct Vec16 {
+    u32x4 v;
+};
+
+template <typename T, bool RC, bool ALIGNED>
+__device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ld, int x0, int xtot, int r0,
+                                          int rend, Vec16 (&regs)[4]) {
+    constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
+    constexpr int VPR = RC ? (BK / VEC) : (BM / VEC);  // vectors per LDS row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = threadIdx.x + NT * i;
+        const int row = v / VPR, cv = v % VPR;
+        int x, r;
+        int64_t off;
+        bool full, any;
+        if (RC) {
+            x = x0 + row;
+            r = r0 + cv * VEC;
+            off = (int64_t)x * ld + r;
+            any = (x < xtot) && (r < rend);
+            full = any && (r + VEC <= rend);
+        } else {
+            r = r0 + row;
+            x = x0 + cv * VEC;
+            off = (int64_t)r * ld + x;
+            any = (r < rend) && (x < xtot);
+            full = any && (x + VEC <= xtot);
+        }
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (ALIGNED && full) {
+            val = *reinterpret_cast<const u32x4*>(base + off);
+        } else if (any) {
+            const int lim = RC ? (rend - r) : (xtot - x);
+            T tmp[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tmp[e] = (e < lim) ? base[off + e] : T(0);
+            val = *reinterpret_cast<u32x4*>(tmp);
+        }
+        regs[i].v = val;
+    }
+}
+
+template <typename T, bool RC>
+__device__ __forceinline__ void store_tile(T* __restrict__ lds, const Vec16 (&regs)[4]) {
+    constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
+    constexpr int VPR = RC ? (BK / VEC) : (BM / VEC);
+    constexpr int S = RC ? Cfg<T>::S_RC : Cfg<T>::S_XC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = threadIdx.x + NT * i;
+        const int row = v / VPR, cv = v % VPR;
+        T* dst = lds + row * S + cv * VEC;
+        if (sizeof(T) == 4 && RC) {  // stride 33: scalar stores
+            const float* s = reinterpret_cast<const float*>(&regs[i].v);
+            float* d = reinterpret_cast<float*>(dst);
+            d[0] = s[0];
+            d[1] = s[1];
+            d[2] = s[2];
+            d[3] = s[3];
+        } else {
+            *reinterpret_cast<u32x4*>(dst) = regs[i].v;
+        }
+    }
+}
+
+// bf16 fragment (8 values along the reduction for row/col x = xt + (lane&31), k = 8*(lane>>5)+j)
+template <bool RC>
+__device__ __forceinline__ bf16x8 read_frag_bf16(const bf16_t* lds, int xt, int r0, int lane) {
+    if (RC) {
+        const bf16_t* p = lds + (xt + (lane & 31)) * Cfg<bf16_t>::S_RC + r0 + 8 * (lane >> 5);
+        return *reinterpret_cast<const bf16x8*>(p);
+    } else {
+        constexpr int S = Cfg<bf16_t>::S_XC;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3, h = lane >> 5;
+        const bf16_t* p = lds + (r0 + 8 * h + q) * S + xt + 16 * (g & 1) + 4 * p4;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * S));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+template <bool RC>
+__device__ __forceinline__ float read_frag_f32(const float* lds, int xt, int r, int lane) {
+    if (RC) return lds[(xt + (lane & 31)) * Cfg<float>::S_RC + r];
+    return lds[r * Cfg<float>::S_XC + xt + (lane & 31)];
+}
+
+template <typename T, bool A_RC, bool B_RC, bool ALIGNED>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
+    constexpr int BK = Cfg<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* ldsA = reinterpret_cast<T*>(smem);
+    T* ldsB = ldsA + ((tile_elems<T, A_RC>() + 7) & ~7);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int rbeg = split * a.r_per_split;
+    const int rend = min(a.R, rbeg + a.r_per_split);
+    const T* A = reinterpret_cast<const T*>(a.A);
+    const T* B = reinterpret_cast<const T*>(a.B);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Vec16 ra[4], rb[4];
+    const int nt = (rend > rbeg) ? (rend - rbeg + BK - 1) / BK : 0;
+    if (nt > 0) {
+        load_tile<T, A_RC, ALIGNED>(A, a.lda, m0, a.M, rbeg, rend, ra);
+        load_tile<T, B_RC, ALIGNED>(B, a.ldb, n0, a.N, rbeg, rend, rb);
+        store_tile<T, A_RC>(ldsA, ra);
+        store_tile<T, B_RC>(ldsB, rb);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            const int r0 = rbeg + (t + 1) * BK;
+            load_tile<T, A_RC, ALIGNED>(A, a.lda, m0, a.M, r0, rend, ra);
+            load_tile<T, B_RC, ALIGNED>(B, a.ldb, n0, a.N, r0, rend, rb);
+        }
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[i] = read_frag_bf16<A_RC>(reinterpret_cast<const bf16_t*>(ldsA), wm * 64 + i * 32, ks * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[j] = read_frag_bf16<B_RC>(reinterpret_cast<const bf16_t*>(ldsB), wn * 64 + j * 32, ks * 16, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int r = 2 * ks + (lane >> 5);
+                float fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[i] = read_frag_f32<A_RC>(reinterpret_cast<const float*>(ldsA), wm * 64 + i * 32, r, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[j] = read_frag_f32<B_RC>(reinterpret_cast<const float*>(ldsB), wn * 64 + j * 32, r, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nt) {
+            store_tile<T, A_RC>(ldsA, ra);
+            store_tile<T, B_RC>(ldsB, rb);
+        }
+        __syncthreads();
+    }
+
+    const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
+    float* C = a.C + (int64_t)split * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const float bv = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < a.M && col < a.N) C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + bv;
+            }
+        }
+}
+
+template <typename T, bool A_RC, bool B_RC>
+static int launch_gemm(const GemmArgs& a, int nslab, hipStream_t stream) {
+    constexpr int VEC = Cfg<T>::VEC;
+    const bool aligned = aligned16(a.A) && aligned16(a.B) && (a.lda % VEC == 0) && (a.ldb % VEC == 0);
+    const size_t lds = (((size_t)tile_elems<T, A_RC>() + 7) & ~size_t(7)) * sizeof(T) +
+                       (size_t)tile_elems<T, B_RC>() * sizeof(T);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nslab);
+    if (aligned)
+        hipLaunchKernelGGL((gemm_kernel<T, A_RC, B_RC, true>), grid, dim3(NT), lds, stream, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, A_RC, B_RC, false>), grid, dim3(NT), lds, stream, a);
+    return 0;
+}
+
+static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream_t stream) {
+    const int BK = dtype == C2_BF16 ? Cfg<bf16_t>::BK : Cfg<float>::BK;
+    int64_t per = (a.R + nslab - 1) / nslab;
+    per = (per + BK - 1) / BK * BK;
+    a.r_per_split = (int)per;
+    if (dtype == C2_BF16) {
+        if (layout == 0) return launch_gemm<bf16_t, true, true>(a, nslab, stream);
+        if (layout == 1) return launch_gemm<bf16_t, true, false>(a, nslab, stream);
+        return launch_gemm<bf16_t, false, false>(a, nslab, stream);
+    } else {
+        if (layout == 0) return launch_gemm<float, true, true>(a, nslab, stream);
+        if (layout == 1) return launch_gemm<float, true, false>(a, nslab, stream);
+        return launch_gemm<float, false, false>(a, nslab, stream);
+    }
+}
+
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int64_t stride, float* __restrict__ out,
+                                 int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) {
+    return (dtype == C2_F32 || dtype == C2_BF16) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
+           M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
+}
+
+extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
+                             int64_t K, float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
+                             void* stream) {
+    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK(A && W && Y, "null pointer");
+    C2_CHECK(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
+    C2_CHECK(!(bias && nslab != 1), "bias needs nslab == 1");
+    C2_CHECK(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0};
+    gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, int dtype, int64_t M,
+                               int64_t N, int64_t K, float* dA, int64_t ldda, int nslab, int64_t slab_stride,
+                               const float* alpha_dev, void* stream) {
+    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK(dY && W && dA, "null pointer");
+    C2_CHECK(lddy >= N && ldw >= K && ldda >= K, "leading dimension too small");
+    C2_CHECK(nslab == 1 || slab_stride >= M * ldda, "slab_stride too small");
+    if (M == 0 || K == 0) return 0;
+    // C[m][k] = sum_n dY[m][n] W[n][k]:  A-op = dY (RC over n), B-op = W ([n][k]: XC, output index k contiguous)
+    GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0};
+    gemm_dispatch(1, dtype, a, nslab, (hipStream_t)stream);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, int dtype, int64_t M,
+                               int64_t N, int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
+                               const float* alpha_dev, void* stream) {
+    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK(dY && A && dW, "null pointer");
+    C2_CHECK(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
+    C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
+    if (N == 0 || K == 0) return 0;
+    // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
+    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0};
+    gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n,
+                            void* stream) {
+    C2_CHECK(slabs && out && nslab >= 1 && n >= 0, "bad arguments");
+    if (n == 0) return 0;
+    int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslab, slab_stride,
+                       out, n);
+    C2_LAUNCH_CHECK();
+    return 0;
+}

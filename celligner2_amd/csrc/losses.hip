@@ -1,0 +1,477 @@
+// Reconstruction (NB / MSE) and classifier losses: forward and analytic backward fused in one pass.
+//
+// NB kernel layout: one workgroup walks whole rows (cells); thread t owns the same gene columns in every row it
+// visits, so (a) the row's softmax statistics are two block reductions over register-held logits, (b) the
+// per-gene dispersion gradient is accumulated in registers across the workgroup's rows and leaves the kernel
+// as one partial row per workgroup (summed by a second tiny kernel: deterministic, no atomics).  HBM traffic
+// per cell = logits 4G + x 4G + goodloc 1G read, dlogits (2|4)G written: the algorithmic minimum.
+#include "common.h"
+
+namespace c2 {
+
+// ---- special functions (x > 0) -------------------------------------------------------------------------
+// lgamma by an 8-step upward shift for z < 8 and the Stirling series; |err| ~ 1e-7 relative to the terms.
+__device__ __forceinline__ float lgamma_pos(float z) {
+    const bool small = z < 8.0f;
+    float prod = 1.0f;
+    float zs = z;
+    if (small) {
+        prod = z * (z + 1.f) * (z + 2.f) * (z + 3.f);
+        prod *= (z + 4.f) * (z + 5.f) * (z + 6.f) * (z + 7.f);
+        zs = z + 8.0f;
+    }
+    const float r = 1.0f / zs;
+    const float r2 = r * r;
+    // 1/12 - r2/360 + r4/1260 - r6/1680
+    const float series = r * (0.083333333333f + r2 * (-0.002777777778f + r2 * (0.000793650794f - r2 * 0.000595238095f)));
+    float res = (zs - 0.5f) * logf(zs) - zs + 0.918938533205f + series;
+    if (small) res -= logf(prod);
+    return res;
+}
+
+// digamma by a 6-step shift (as one rational term) and the asymptotic series.
+__device__ __forceinline__ float digamma_pos(float z) {
+    float corr = 0.f;
+    float zs = z;
+    if (z < 6.0f) {
+        // sum_{k<6} 1/(z+k) = P'(z)/P(z), P = prod (z+k)
+        float P = z, dP = 1.f;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            const float t = z + (float)k;
+            dP = dP * t + P;
+            P = P * t;
+        }
+        corr = dP / P;
+        zs = z + 6.0f;
+    }
+    const float r = 1.0f / zs;
+    const float r2 = r * r;
+    // ln z - 1/(2z) - 1/(12 z^2) + 1/(120 z^4) - 1/(252 z^6) + 1/(240 z^8)
+    const float series = r2 * (0.083333333333f - r2 * (0.008333333333f - r2 * (0.003968253968f - r2 * 0.004166666667f)));
+    return logf(zs) - 0.5f * r - series - corr;
+}
+
+// ---- NB: per-(pattern, gene) constants -----------------------------------------------------------------
+// pattern 0: the row holds only 0s  -> q = e0;  1: only 1s -> q = e1;  2: both -> q = e0 + e1
+// (celligner2/model/_utils.py:19-24 scatter_ quirk).  tab: [3][3][G] = {theta, K1, K2}
+//   K1 = theta*log(theta+eps) - lgamma(theta),  K2 = log(theta+eps) + theta/(theta+eps) - digamma(theta)
+__global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, float* __restrict__ tab) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float t0 = theta[g * C + 0];
+    const float t1 = C > 1 ? theta[g * C + 1] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float t = p == 0 ? t0 : (p == 1 ? t1 : t0 + t1);
+        const float th = expf(t);
+        const float lte = logf(th + 1e-8f);
+        tab[(p * 3 + 0) * G + g] = th;
+        tab[(p * 3 + 1) * G + g] = th * lte - lgamma_pos(th);
+        tab[(p * 3 + 2) * G + g] = lte + th / (th + 1e-8f) - digamma_pos(th);
+    }
+}
+
+struct NbArgs {
+    const float* logits;
+    const float* x;
+    const uint8_t* goodloc;
+    const float* sizefactor;
+    const int64_t* cond;
+    const float* tab;
+    void* dlogits;
+    float* part_dt;    // [ngroups][3][G]
+    int* part_flag;    // [ngroups][3]
+    float* part_loss;  // [ngroups]
+    int32_t* status;
+    int64_t ldl, ldx, ldg, lddl, B, G;
+    int C;
+    float inv_B;
+};
+
+template <typename TD, int NT, int NV, bool VEC>
+__global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
+    __shared__ float red[32];
+    constexpr int NE = NV * 4;
+    const int tid = threadIdx.x;
+    const int64_t G = a.G;
+    // column of element e of this thread
+    auto col_of = [&](int e) -> int64_t {
+        if (VEC) return 4ll * (tid + NT * (e >> 2)) + (e & 3);
+        return (int64_t)tid + (int64_t)NT * e;
+    };
+    float dacc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) dacc[e] = 0.f;
+    int cur_pat = -1;
+    int flushed = 0;
+    float loss_acc = 0.f;
+    const float eps = 1e-8f;
+
+    auto flush = [&](int pat) {
+        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
+        const bool first = !((flushed >> pat) & 1);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int64_t c = col_of(e);
+            if (c < G) dst[c] = first ? dacc[e] : dst[c] + dacc[e];
+            dacc[e] = 0.f;
+        }
+        flushed |= 1 << pat;
+    };
+
+    for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
+        // ---- pattern of the row (uniform over the block)
+        int has0 = 0, has1 = 0, bad = 0;
+        for (int j = 0; j < a.C; ++j) {
+            const int64_t v = a.cond[row * a.C + j];
+            has0 |= (v == 0);
+            has1 |= (v == 1);
+            bad |= (v < 0) | (v > 1) | (v >= a.C);
+        }
+        if (bad || (!has0 && !has1)) {
+            if (tid == 0) *a.status = 1;
+            continue;
+        }
+        const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
+        if (pat != cur_pat) {
+            if (cur_pat >= 0) flush(cur_pat);
+            cur_pat = pat;
+        }
+        const float* orow = a.logits + row * a.ldl;
+        const float* xrow = a.x + row * a.ldx;
+        const uint8_t* grow = a.goodloc + row * a.ldg;
+        const float sf = a.sizefactor[row];
+        // ---- pass A: logits -> registers, row max, exp, row sum
+        float ev[NE];
+        float mx = -INFINITY;
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int64_t c = 4ll * (tid + NT * i);
+                f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (c < G) v = *reinterpret_cast<const f32x4*>(orow + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ev[i * 4 + k] = v[k];
+                    mx = fmaxf(mx, v[k]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int64_t c = col_of(e);
+                ev[e] = c < G ? orow[c] : -INFINITY;
+                mx = fmaxf(mx, ev[e]);
+            }
+        }
+        mx = block_max<NT>(mx, red);
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            ev[e] = __expf(ev[e] - mx);  // exp(-inf) = 0 for padding
+            sm += ev[e];
+        }
+        sm = block_sum<NT>(sm, red);
+        const float inv_sum = 1.0f / sm;
+        // ---- pass B: log-likelihood, gradient pieces
+        float pg[NE];  // p * gp
+        float S = 0.f;
+        const float* tb_th = a.tab + (int64_t)(pat * 3 + 0) * G;
+        const float* tb_k1 = a.tab + (int64_t)(pat * 3 + 1) * G;
+        const float* tb_k2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float scale = -a.inv_B;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float xv[4], thv[4], k1v[4], k2v[4];
+            unsigned mbits = 0;
+            const int64_t c0 = VEC ? 4ll * (tid + NT * i) : 0;
+            if (VEC) {
+                f32x4 xx = {0.f, 0.f, 0.f, 0.f}, t0 = {1.f, 1.f, 1.f, 1.f}, t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+                if (c0 < G) {
+                    xx = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    t0 = *reinterpret_cast<const f32x4*>(tb_th + c0);
+                    t1 = *reinterpret_cast<const f32x4*>(tb_k1 + c0);
+                    t2 = *reinterpret_cast<const f32x4*>(tb_k2 + c0);
+                    mbits = *reinterpret_cast<const unsigned*>(grow + c0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xv[k] = xx[k]; thv[k] = t0[k]; k1v[k] = t1[k]; k2v[k] = t2[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t c = col_of(i * 4 + k);
+                    const bool in = c < G;
+                    xv[k] = in ? xrow[c] : 0.f;
+                    thv[k] = in ? tb_th[c] : 1.f;
+                    k1v[k] = in ? tb_k1[c] : 0.f;
+                    k2v[k] = in ? tb_k2[c] : 0.f;
+                    mbits |= (in && grow[c]) ? (1u << (8 * k)) : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = i * 4 + k;
+                const bool m = (mbits >> (8 * k)) & 0xffu;
+                const float p = ev[e] * inv_sum;
+                const float mu = sf * p;
+                const float th = thv[k], x = xv[k];
+                const float tm = th + mu + eps;
+                const float ltm = logf(tm);
+                const float lme = logf(mu + eps);
+                const float zt = x + th;
+                // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
+                const float ll = k1v[k] - zt * ltm + x * lme + lgamma_pos(zt) - lgamma_pos(x + 1.0f);
+                const float rtm = 1.0f / tm;
+                // p*gp = -(m/B) * mu * dll/dmu,  dll/dmu = x/(mu+eps) - (theta+x)/(theta+mu+eps)
+                const float dmu_mu = x * mu / (mu + eps) - zt * mu * rtm;
+                // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
+                const float dth = k2v[k] - ltm - zt * rtm + digamma_pos(zt);
+                const float a_pg = m ? scale * dmu_mu : 0.f;
+                pg[e] = a_pg;
+                S += a_pg;
+                ev[e] = p;
+                loss_acc += m ? ll : 0.f;
+                dacc[e] += m ? scale * th * dth : 0.f;
+            }
+        }
+        S = block_sum<NT>(S, red);
+        // ---- pass C: dlogits = p*gp - p*S
+        TD* drow = reinterpret_cast<TD*>(a.dlogits) + row * a.lddl;
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int64_t c = 4ll * (tid + NT * i);
+                if (c < G) {
+                    float d[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = pg[i * 4 + k] - ev[i * 4 + k] * S;
+                    if (sizeof(TD) == 4) {
+                        f32x4 o = {d[0], d[1], d[2], d[3]};
+                        *reinterpret_cast<f32x4*>(drow + c) = o;
+                    } else {
+                        u32x2 pk;
+                        pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
+                        pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
+                        *reinterpret_cast<u32x2*>(drow + c) = pk;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int64_t c = col_of(e);
+                if (c < G) st_from_f32<TD>(drow + c, pg[e] - ev[e] * S);
+            }
+        }
+    }
+    if (cur_pat >= 0) flush(cur_pat);
+    loss_acc = block_sum<NT>(loss_acc, red);
+    if (tid == 0) {
+        a.part_loss[blockIdx.x] = -a.inv_B * loss_acc;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.part_flag[blockIdx.x * 3 + p] = (flushed >> p) & 1;
+    }
+}
+
+__global__ void nb_dtheta_kernel(const float* __restrict__ part_dt, const int* __restrict__ part_flag, int ngroups,
+                                 int64_t G, int C, float* __restrict__ dtheta) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int grp = 0; grp < ngroups; ++grp) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (part_flag[grp * 3 + p]) s[p] += part_dt[((int64_t)grp * 3 + p) * G + g];
+    }
+    for (int j = 0; j < C; ++j) {
+        float v = 0.f;
+        if (j == 0) v = s[0] + s[2];
+        if (j == 1) v = s[1] + s[2];
+        dtheta[g * C + j] = v;
+    }
+}
+
+constexpr int kNbMaxGroups = 512;
+
+// ---- MSE ---------------------------------------------------------------------------------------------------
+template <typename TD>
+__global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                          const float* __restrict__ x, int64_t ldx,
+                                                          const uint8_t* __restrict__ goodloc, int64_t ldg, int64_t B,
+                                                          int64_t G, float inv_B, TD* __restrict__ dl, int64_t lddl,
+                                                          float* __restrict__ partials) {
+    __shared__ float red[32];
+    float acc = 0.f;
+    const int64_t total = B * G;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / G, g = i - b * G;
+        const float o = logits[b * ldl + g];
+        const float r = fmaxf(o, 0.f);
+        const float m = goodloc[b * ldg + g] ? 1.f : 0.f;
+        const float d = r - x[b * ldx + g];
+        acc += m * d * d;
+        st_from_f32<TD>(dl + b * lddl + g, (o > 0.f) ? 2.f * inv_B * m * d : 0.f);
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc * inv_B;
+}
+
+// ---- classifier loss: wave per row -------------------------------------------------------------------------
+template <typename TD>
+__global__ __launch_bounds__(256) void classifier_loss_kernel(const float* __restrict__ u, int64_t ldu,
+                                                              int64_t* __restrict__ classes, int64_t B, int P,
+                                                              float bc, TD* __restrict__ du, int64_t lddu,
+                                                              float* __restrict__ partials) {
+    __shared__ float red[32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int64_t row = blockIdx.x * 4ll + wv; row < B; row += gridDim.x * 4ll) {
+        const float* ur = u + row * ldu;
+        int64_t* yr = classes + row * P;
+        float mx = -INFINITY;
+        for (int c = lane; c < P; c += 64) mx = fmaxf(mx, ur[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < P; c += 64) se += expf(ur[c] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        float ent = 0.f, ce = 0.f;
+        for (int c = lane; c < P; c += 64) {
+            const float v = ur[c];
+            const float logp = v - lse;
+            ent -= expf(logp) * logp;
+            const int64_t y = yr[c];
+            const float w = (y == -1) ? 0.f : 1.f;
+            const float yt = (y == -1) ? 0.f : (float)y;
+            const float sp = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+            ce += w * (sp - yt * v);
+        }
+        ent = wave_sum(ent);
+        ce = wave_sum(ce);
+        for (int c = lane; c < P; c += 64) {
+            const float v = ur[c];
+            const float logp = v - lse;
+            const float p = expf(logp);
+            const int64_t y = yr[c];
+            const float w = (y == -1) ? 0.f : 1.f;
+            const float yt = (y == -1) ? 0.f : (float)y;
+            const float sig = 1.0f / (1.0f + expf(-v));
+            const float g = bc * w * (sig - yt) + (1.f - bc) * (-p * (logp + ent));
+            st_from_f32<TD>(du + row * lddu + c, g);
+            if (y == -1) yr[c] = 0;  // the reference mutates the caller's tensor (losses.py:324-325)
+        }
+        if (lane == 0) acc += bc * ce + (1.f - bc) * ent;
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
+    (void)C;
+    const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
+    // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
+    return (size_t)(9 * G + ng * 3 * G + ng * 3 + ng + 64);
+}
+
+template <typename TD>
+static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
+    const int64_t G = a.G;
+#define NB_L(NT, NV)                                                                                       \
+    do {                                                                                                   \
+        if (vec) hipLaunchKernelGGL((nb_fwd_bwd_kernel<TD, NT, NV, true>), dim3(ngroups), dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((nb_fwd_bwd_kernel<TD, NT, NV, false>), dim3(ngroups), dim3(NT), 0, st, a);    \
+    } while (0)
+    if (G <= 1024) NB_L(256, 1);
+    else if (G <= 2048) NB_L(256, 2);
+    else if (G <= 4096) NB_L(256, 4);
+    else if (G <= 8192) NB_L(1024, 2);
+    else if (G <= 12288) NB_L(1024, 3);
+    else if (G <= 16384) NB_L(1024, 4);
+    else if (G <= 20480) NB_L(1024, 5);
+    else if (G <= 24576) NB_L(1024, 6);
+    else if (G <= 32768) NB_L(1024, 8);
+    else return 1;
+#undef NB_L
+    return 0;
+}
+
+extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+                                   const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
+                                   const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
+                                   void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
+                                   int32_t* status_dev, void* stream) {
+    C2_CHECK(logits && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dtheta && ws && status_dev,
+             "null pointer");
+    C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(C >= 1, "NB needs at least one condition column (theta is [G,C])");
+    C2_CHECK(ldl >= G && ldx >= G && ldg >= G && lddl >= G, "leading dimension too small");
+    C2_CHECK(G <= 32768, "G > 32768 genes is not supported by the NB kernel yet");
+    if (B == 0 || G == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
+    float* tab = ws;
+    float* part_dt = tab + 9 * G;
+    int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
+    float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
+    NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
+             ldl, ldx, ldg, lddl, B, G, C, inv_B};
+    const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
+                     (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
+                     (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
+    int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
+    C2_CHECK(rc == 0, "unsupported G");
+    hipLaunchKernelGGL(nb_dtheta_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part_dt, part_flag, ngroups,
+                       G, C, dtheta);
+    launch_finalize_sum(part_loss, ngroups, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_recon_mse_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+                                    const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G, float inv_B,
+                                    float* loss_out, void* dlogits, int dl_dtype, int64_t lddl, float* ws,
+                                    void* stream) {
+    C2_CHECK(logits && x && goodloc && loss_out && dlogits && ws, "null pointer");
+    C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(ldl >= G && ldx >= G && ldg >= G && lddl >= G, "leading dimension too small");
+    if (B == 0 || G == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((B * G + 255) / 256, 2048));
+    if (dl_dtype == C2_BF16)
+        hipLaunchKernelGGL((mse_fwd_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, logits, ldl, x, ldx, goodloc, ldg, B,
+                           G, inv_B, (bf16_t*)dlogits, lddl, ws);
+    else
+        hipLaunchKernelGGL((mse_fwd_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, logits, ldl, x, ldx, goodloc, ldg, B,
+                           G, inv_B, (float*)dlogits, lddl, ws);
+    launch_finalize_sum(ws, grid, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_classifier_loss_fwd_bwd(const float* u, int64_t ldu, int64_t* classes, int64_t B, int P,
+                                          float betaclass, float* loss_out, void* du, int du_dtype, int64_t lddu,
+                                          float* ws, void* stream) {
+    C2_CHECK(loss_out && ws, "null pointer");
+    C2_CHECK(du_dtype == C2_F32 || du_dtype == C2_BF16, "bad dtype");
+    if (B == 0 || P == 0) return 0;  // zero-width classifier: loss 0 (celligner2.py:350-356 with P = 0)
+    C2_CHECK(u && classes && du && ldu >= P && lddu >= P, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((B + 3) / 4, 2048));
+    if (du_dtype == C2_BF16)
+        hipLaunchKernelGGL((classifier_loss_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, u, ldu, classes, B, P, betaclass,
+                           (bf16_t*)du, lddu, ws);
+    else
+        hipLaunchKernelGGL((classifier_loss_kernel<float>), dim3(grid), dim3(256), 0, st, u, ldu, classes, B, P, betaclass,
+                           (float*)du, lddu, ws);
+    launch_finalize_sum(ws, grid, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,375 @@
+// Multi-dataset MMD (celligner2/model/losses.py:127-249, _utils.py:27-36) for gfx950.
+//
+// The reference partitions the latent rows by unique condition row and sums, over pairs of partitions,
+//   mean K(X,X) + mean K(Y,Y) - 2 mean K(X,Y),   K = sum over 19 bandwidths of exp(-|a-b|^2 / (2 alpha)).
+// Here that is ONE weighted double sum over all row pairs,  sum_{a,b} wt[part(a)][part(b)] * K(f_a,f_b):
+//   c2_partition      -> part id per row (torch.unique(dim=0) order) + the pair-weight table wt
+//   c2_mmd_fwd_bwd    -> 32x32 pair tiles; the Gram block and the gradient contraction sum_j gw_ij f_j both run
+//                        on v_mfma_f32_32x32x2_f32 (exact fp32 products), the 19-scale exp sum on the VALU;
+//                        every self block is computed once however many pairs use it.
+// Rows may be a local shard [row0,row0+Bl) against the all-gathered Bg rows (data-parallel MMD): by symmetry of K
+// the local rows' full gradient needs only their own row block, so no backward collective exists.
+#include "common.h"
+
+namespace c2 {
+
+constexpr int MAXP = C2_MMD_MAX_PARTS;
+
+__device__ const float c_mmd_alphas[19] = {1e-6f, 1e-5f, 1e-4f, 1e-3f, 1e-2f, 1e-1f, 1.f,  5.f,  10.f, 15.f,
+                                       20.f,  25.f,  30.f,  35.f,  100.f, 1e3f,  1e4f, 1e5f, 1e6f};
+
+// ---------------------------------------------------------------------------------------------------------
+// partition: single block
+__global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restrict__ cond, int64_t B, int C,
+                                                         int n_conditions, int main_col, int boundary,
+                                                         int32_t* __restrict__ part_id, float* __restrict__ wt,
+                                                         unsigned long long* __restrict__ keys,
+                                                         int32_t* __restrict__ status) {
+    __shared__ unsigned long long s_red[16];
+    __shared__ unsigned long long s_uniq[MAXP];
+    __shared__ int s_map[MAXP];
+    __shared__ int s_cnt[MAXP];
+    __shared__ int s_n, s_bad, s_nparts;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_n = 0; s_bad = 0; s_nparts = 0; }
+    for (int i = tid; i < MAXP; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    // keys: column 0 is the most significant bit -> numeric order == lexicographic row order
+    int bad = 0;
+    for (int64_t r = tid; r < B; r += 1024) {
+        unsigned long long k = 0;
+        for (int j = 0; j < C; ++j) {
+            const int64_t v = cond[r * C + j];
+            bad |= (v != 0 && v != 1);
+            k = (k << 1) | (unsigned long long)(v == 1);
+        }
+        keys[r] = k;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    // unique keys ascending by repeated min-extraction
+    const unsigned long long NONE = ~0ull;
+    unsigned long long cur = 0;
+    bool have_cur = false;
+    for (int it = 0; it <= MAXP; ++it) {
+        unsigned long long m = NONE;
+        for (int64_t r = tid; r < B; r += 1024) {
+            const unsigned long long k = keys[r];
+            if ((!have_cur || k > cur) && k < m) m = k;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(m, o, 64);
+            m = other < m ? other : m;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = m;
+        __syncthreads();
+        m = s_red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = s_red[i] < m ? s_red[i] : m;
+        if (m == NONE) break;
+        if (it == MAXP) {  // more than MAXP distinct rows
+            if (tid == 0) s_bad = 1;
+            break;
+        }
+        if (tid == 0) { s_uniq[it] = m; s_n = it + 1; }
+        cur = m;
+        have_cur = true;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0) {
+        // partition order: [cat(main rows)] + the rest ascending (_utils.py:31-36)
+        int np = 0;
+        if (main_col >= 0) {
+            bool any_main = false;
+            for (int u = 0; u < n; ++u)
+                if ((s_uniq[u] >> (C - 1 - main_col)) & 1ull) any_main = true;
+            if (!any_main) s_bad = 1;  // torch.cat([]) raises in the reference
+            np = 1;
+            for (int u = 0; u < n; ++u) {
+                if ((s_uniq[u] >> (C - 1 - main_col)) & 1ull) s_map[u] = 0;
+                else s_map[u] = np++;
+            }
+        } else {
+            for (int u = 0; u < n; ++u) s_map[u] = np++;
+        }
+        s_nparts = np;
+    }
+    __syncthreads();
+    for (int64_t r = tid; r < B; r += 1024) {
+        const unsigned long long k = keys[r];
+        int u = 0;
+        for (; u < n; ++u)
+            if (s_uniq[u] == k) break;
+        const int p = (u < n) ? s_map[u] : 0;
+        part_id[r] = p;
+        atomicAdd(&s_cnt[p], 1);
+    }
+    for (int i = tid; i < MAXP * MAXP; i += 1024) wt[i] = 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        const int np = s_nparts;
+        auto add_pair = [&](int i, int j) {
+            const float ni = (float)s_cnt[i], nj = (float)s_cnt[j];
+            wt[i * MAXP + i] += 1.f / (ni * ni);
+            wt[j * MAXP + j] += 1.f / (nj * nj);
+            wt[i * MAXP + j] -= 1.f / (ni * nj);
+            wt[j * MAXP + i] -= 1.f / (ni * nj);
+        };
+        if (boundary >= 0) {  // losses.py:232-238
+            for (int i = 0; i < boundary; ++i)
+                for (int j = boundary; j < n_conditions; ++j) {
+                    if (i >= np || j >= np) { s_bad = 1; continue; }  // IndexError in the reference
+                    if (s_cnt[i] < 2 || s_cnt[j] < 2) continue;
+                    add_pair(i, j);
+                }
+        } else {  // losses.py:240-248
+            for (int i = 0; i < np; ++i) {
+                if (s_cnt[i] < 1) continue;
+                for (int j = 0; j < i; ++j) {
+                    if (s_cnt[j] < 1) continue;
+                    if (main_col >= 0 && j != 0) continue;
+                    add_pair(i, j);
+                }
+            }
+        }
+        if (s_bad) *status = 2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename TF>
+__global__ void row_norms_kernel(const TF* __restrict__ f, int64_t ldf, int64_t Bg, int D, float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= Bg) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = ld_as_f32<TF>(f + row * ldf + d);
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) norms[row] = s;
+}
+
+constexpr int TS = 32;      // pair tile edge
+constexpr int DC = 64;      // feature chunk staged in LDS
+constexpr int LDT = DC + 1; // LDS row stride of a feature tile
+
+// one wave per block; block (it, js, dchunk)
+template <typename TF>
+__global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, int64_t ldf,
+                                                      const int32_t* __restrict__ part_id,
+                                                      const float* __restrict__ wt, const float* __restrict__ norms,
+                                                      int64_t row0, int64_t Bl, int64_t Bg, int D, int jt_per,
+                                                      float beta, float* __restrict__ loss_partials,
+                                                      float* __restrict__ gslabs /*[jsplit][Bl][D]*/) {
+    __shared__ float ldsI[TS * LDT];
+    __shared__ float ldsJ[TS * LDT];
+    __shared__ float ldsW[TS * (TS + 1)];
+    const int lane = threadIdx.x;
+    const int it = blockIdx.x, js = blockIdx.y, dchunk = blockIdx.z;
+    const int64_t i0 = (int64_t)it * TS;  // local row index of the tile
+    const int hi = lane >> 5, lo = lane & 31;
+    const int nchunks = (D + DC - 1) / DC;
+    const int dgrad0 = dchunk * DC;  // gradient columns owned by this block
+
+    // per-lane row metadata (16 rows) and its norms/parts
+    float ni[16];
+    int pi[16];
+    int64_t gi[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
+        const int64_t li = i0 + r;
+        gi[e] = row0 + li;
+        const bool ok = li < Bl;
+        ni[e] = ok ? norms[gi[e]] : 0.f;
+        pi[e] = ok ? part_id[gi[e]] : -1;
+    }
+    auto stage = [&](float* dst, int64_t grow0, int64_t nrows_total, int d0) {
+        // 32 rows x 64 cols, lane covers (row = k*? ...) coalesced: 16 lanes per row (4 floats each)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = lane + 64 * k;  // 0..511
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t gr = grow0 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = d0 + c4 + q;
+                float v = 0.f;
+                if (gr < nrows_total && d < D) v = ld_as_f32<TF>(f + gr * ldf + d);
+                dst[r * LDT + c4 + q] = v;
+            }
+        }
+    };
+
+    f32x16 gacc[2];
+    float racc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { gacc[0][e] = 0.f; gacc[1][e] = 0.f; racc[e] = 0.f; }
+    float lacc = 0.f;
+
+    const int64_t njt = (Bg + TS - 1) / TS;
+    const int64_t jt_beg = (int64_t)js * jt_per, jt_end = min(njt, jt_beg + jt_per);
+    if (nchunks == 1) {
+        stage(ldsI, row0 + i0, row0 + Bl, 0);
+    }
+    for (int64_t jt = jt_beg; jt < jt_end; ++jt) {
+        const int64_t j0 = jt * TS;
+        // ---- Gram block via fp32 MFMA
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();
+            if (nchunks > 1) stage(ldsI, row0 + i0, row0 + Bl, ch * DC);
+            stage(ldsJ, j0, Bg, ch * DC);
+            __syncthreads();
+#pragma unroll 8
+            for (int s = 0; s < DC / 2; ++s) {
+                const float a = ldsI[lo * LDT + 2 * s + hi];
+                const float b = ldsJ[lo * LDT + 2 * s + hi];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+        // ---- kernel sums for this lane's 16 (i, j) pairs; column j = j0 + lo
+        const int64_t gj = j0 + lo;
+        const bool jok = gj < Bg;
+        const float nj = jok ? norms[gj] : 0.f;
+        const int pj = jok ? part_id[gj] : -1;
+        float gw[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float w = 0.f;
+            if (jok && pi[e] >= 0) w = wt[pi[e] * MAXP + pj];
+            float d = fmaxf(ni[e] + nj - 2.f * acc[e], 0.f);
+            if (gi[e] == gj) d = 0.f;  // exact self distance
+            float S = 0.f, Wp = 0.f;
+            if (w != 0.f) {
+#pragma unroll
+                for (int k = 0; k < 19; ++k) {
+                    const float bk = 1.0f / (2.0f * c_mmd_alphas[k]);
+                    const float ex = __expf(-bk * d);
+                    S += ex;
+                    Wp += 2.f * bk * ex;
+                }
+            }
+            lacc += w * S;
+            // a self pair adds K = 19 to the loss but no gradient (f_i - f_i = 0): drop its 1e6-scale weight,
+            // which would otherwise only cancel to fp32 rounding in G_i - r_i f_i
+            gw[e] = (gi[e] == gj) ? 0.f : w * Wp;
+            racc[e] += gw[e];
+        }
+        // ---- gradient contraction  G_i += sum_j gw_ij f_j  (columns dgrad0 .. dgrad0+63)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            ldsW[r * (TS + 1) + lo] = gw[e];
+        }
+        if (nchunks > 1) stage(ldsJ, j0, Bg, dgrad0);
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < TS / 2; ++s) {
+            const float a = ldsW[lo * (TS + 1) + 2 * s + hi];
+            const float b0 = ldsJ[(2 * s + hi) * LDT + lo];
+            const float b1 = ldsJ[(2 * s + hi) * LDT + 32 + lo];
+            gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, gacc[1], 0, 0, 0);
+        }
+    }
+    // ---- finish: r_i over the 32 column lanes, dfeat = 2*beta*(G_i - r_i f_i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) racc[e] += __shfl_xor(racc[e], o, 64);
+    }
+    __syncthreads();
+    if (nchunks > 1) stage(ldsI, row0 + i0, row0 + Bl, dgrad0);
+    __syncthreads();
+    float* slab = gslabs + (int64_t)js * Bl * D;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            const int64_t li = i0 + r;
+            const int dcol = dgrad0 + h * 32 + lo;
+            if (li < Bl && dcol < D) {
+                const float fi = ldsI[r * LDT + h * 32 + lo];
+                slab[li * D + dcol] = 2.f * beta * (gacc[h][e] - racc[e] * fi);
+            }
+        }
+    lacc = wave_sum(lacc);
+    if (lane == 0 && dchunk == 0) loss_partials[(int64_t)js * gridDim.x + it] = beta * lacc;
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+extern "C" size_t c2_partition_ws(int64_t B) { return (size_t)(B * 8 + 64); }
+
+extern "C" int c2_partition(const int64_t* cond, int64_t B, int C, int n_conditions, int main_col, int boundary,
+                            int32_t* part_id, float* wt, void* ws, int32_t* status_dev, void* stream) {
+    C2_CHECK(cond && part_id && wt && ws && status_dev, "null pointer");
+    C2_CHECK(C >= 1 && C <= 64, "MMD partition supports 1..64 condition columns");
+    C2_CHECK(main_col < C, "main_col out of range");
+    C2_CHECK(B >= 1, "empty batch");
+    hipLaunchKernelGGL(partition_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cond, B, C, n_conditions,
+                       main_col, boundary, part_id, wt, (unsigned long long*)ws, status_dev);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+static void mmd_split(int64_t Bl, int64_t Bg, int& nit, int& jsplit, int& jt_per) {
+    nit = (int)((Bl + TS - 1) / TS);
+    const int64_t njt = (Bg + TS - 1) / TS;
+    int64_t js = std::max<int64_t>(1, std::min<int64_t>(njt, (4096 + nit - 1) / nit));
+    while ((int64_t)nit * js > kReduceWsFloats && js > 1) --js;
+    jt_per = (int)((njt + js - 1) / js);
+    jsplit = (int)((njt + jt_per - 1) / jt_per);
+}
+
+extern "C" size_t c2_mmd_ws(int64_t Bl, int64_t Bg, int64_t D) {
+    int nit, jsplit, jt_per;
+    mmd_split(Bl, Bg, nit, jsplit, jt_per);
+    return (size_t)(Bg + kReduceWsFloats + (int64_t)jsplit * Bl * D + 64);
+}
+
+extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
+                              int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out,
+                              float* dfeat, int64_t lddf, float* ws, void* stream) {
+    C2_CHECK(feat && part_id && wt && loss_out && dfeat && ws, "null pointer");
+    C2_CHECK(f_dtype == C2_F32 || f_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(ldf >= D && lddf >= D && row0 >= 0 && row0 + Bl <= Bg, "bad shape");
+    C2_CHECK(lddf == D, "dfeat must be dense [Bl, D]");
+    if (Bl == 0 || D == 0) return 0;
+    int nit, jsplit, jt_per;
+    mmd_split(Bl, Bg, nit, jsplit, jt_per);
+    C2_CHECK((int64_t)nit * jsplit <= kReduceWsFloats && nit < 65536, "batch too large for the MMD reduction workspace");
+    hipStream_t st = (hipStream_t)stream;
+    float* norms = ws;
+    float* partials = norms + Bg;
+    float* slabs = partials + kReduceWsFloats;
+    const int ndch = (int)((D + DC - 1) / DC);
+    dim3 grid(nit, jsplit, ndch);
+    if (f_dtype == C2_BF16) {
+        hipLaunchKernelGGL((row_norms_kernel<bf16_t>), dim3((unsigned)((Bg + 3) / 4)), dim3(256), 0, st, (const bf16_t*)feat,
+                           ldf, Bg, (int)D, norms);
+        hipLaunchKernelGGL((mmd_tile_kernel<bf16_t>), grid, dim3(64), 0, st, (const bf16_t*)feat, ldf, part_id, wt, norms,
+                           row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
+    } else {
+        hipLaunchKernelGGL((row_norms_kernel<float>), dim3((unsigned)((Bg + 3) / 4)), dim3(256), 0, st, (const float*)feat,
+                           ldf, Bg, (int)D, norms);
+        hipLaunchKernelGGL((mmd_tile_kernel<float>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt, norms, row0,
+                           Bl, Bg, (int)D, jt_per, beta, partials, slabs);
+    }
+    c2_sum_slabs(slabs, jsplit, Bl * D, dfeat, Bl * D, stream);
+    launch_finalize_sum(partials, nit * jsplit, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,434 @@
+"""Host-side driver of one training step: orders the C-ABI kernels of libc2mi.so.
+
+`StepEngine` owns no parameters: it is handed the module's parameter tensors (by state_dict
+name) and keeps only workspaces, bf16 weight shadows and gradient buffers.  It restates, call
+by call, the reference's `Celligner2.forward` (celligner2/model/celligner2.py:259-374) and the
+autograd graph torch builds for it; every FLOP and byte is moved by the HIP kernels.
+
+Precision modes
+  fp32: operands of every GEMM are fp32 (v_mfma_f32_32x32x2_f32, exact fp32 products)
+  bf16: GEMM operands (activations, weight shadows, back-propagated gradients) are bf16,
+        accumulation / losses / parameter gradients / Adam state stay fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+F32 = torch.float32
+
+
+class _Block:
+    """Linear (+bias) (+cond) -> LayerNorm -> ReLU -> Dropout (modules.py:77-107,124-130,298-312)."""
+
+    def __init__(self, name, w, b, wc, drop_name, use_cond):
+        self.name = name  # e.g. "enc0"
+        self.w, self.b, self.wc = w, b, wc  # parameter NAMES (b / wc may be None)
+        self.drop_name = drop_name
+        self.use_cond = use_cond
+        self.gt = F32     # operand dtype of this block's own GEMMs (fwd input, dh, weight)
+        self.out_t = F32  # dtype of its activation = operand dtype of the consumer GEMM
+
+
+class StepEngine:
+    def __init__(self, cfg, params, precision="fp32"):
+        """cfg: dict of model options (see model.Celligner2._cfg); params: {name: Parameter}."""
+        assert precision in ("fp32", "bf16")
+        self.cfg = cfg
+        self.p = params
+        self.precision = precision
+        self.T = F32 if precision == "fp32" else torch.bfloat16
+        self.dev = next(iter(params.values())).device
+        self._ws = {}
+        self._shadow = {}
+        self._shadow_ver = {}
+        self.grad = {}
+        self.world_size, self.rank = 1, 0
+        self.comm = None  # set by parallel.DataParallelStep
+        nh = len(cfg["hidden"])
+        C = cfg["n_conditions"]
+        self.enc = []
+        for i in range(nh):
+            if i == 0:
+                self.enc.append(_Block("enc0", "encoder.FC.L0.expr_L.weight", "encoder.FC.L0.expr_L.bias",
+                                       "encoder.FC.L0.cond_L.weight" if C else None, "enc.D0", bool(C)))
+            else:
+                self.enc.append(_Block(f"enc{i}", f"encoder.FC.L{i}.weight", f"encoder.FC.L{i}.bias", None,
+                                       f"enc.D{i}", False))
+        self.dec = [_Block("dec0", "decoder.FirstL.L0.expr_L.weight", None,
+                           "decoder.FirstL.L0.cond_L.weight" if C else None, "dec.D0", bool(C))]
+        for i in range(1, nh):
+            self.dec.append(_Block(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, f"dec.D{i}", False))
+        self.cls = [_Block("cls0", "classifier.FirstL.L0.weight", None, None, "cls.D0", False)]
+        for i in range(1, len(cfg["cls_hidden"])):
+            self.cls.append(_Block(f"cls{i}", f"classifier.HiddenL.L{i}.weight", None, None, f"cls.D{i}", False))
+        self.head = "decoder.recon_decoder.0" if cfg["recon_loss"] == "mse" else "decoder.mean_decoder.0"
+        # Mixed-precision policy of bf16 mode: only the gene-width GEMMs (>= WIDE on either weight dimension:
+        # encoder L0 and the decoder output layer, 96.6 % of the FLOPs at 19k genes) take bf16 operands; the
+        # narrow hidden GEMMs keep fp32 operands, so the back-propagated signal is rounded to bf16 only where it
+        # meets a gene-width contraction.
+        self.head_t = self.gemm_dtype(self.head + ".weight")
+        chains = (self.enc, self.dec, self.cls)
+        for chain in chains:
+            for blk in chain:
+                blk.gt = self.gemm_dtype(blk.w)
+            for a, b in zip(chain[:-1], chain[1:]):
+                a.out_t = b.gt
+        self.enc[-1].out_t = self.gemm_dtype("encoder.mean_encoder.weight")  # feeds the mean / log-var heads
+        self.dec[-1].out_t = self.head_t
+        self.cls[-1].out_t = self.gemm_dtype("classifier.classifier.0.weight")
+
+    WIDE = 2048
+
+    def gemm_dtype(self, wname):
+        if self.T == F32:
+            return F32
+        return self.T if max(self.p[wname].shape) >= self.WIDE else F32
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, key, shape, dtype=F32):
+        t = self._ws.get(key)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def gbuf(self, name):
+        g = self.grad.get(name)
+        p = self.p[name]
+        if g is None or g.shape != p.shape:
+            g = torch.zeros_like(p, dtype=F32)
+            self.grad[name] = g
+        return g
+
+    def weight(self, name):
+        """GEMM operand view of a weight: the fp32 parameter itself, or its bf16 shadow."""
+        p = self.p[name]
+        if self.gemm_dtype(name) == F32:
+            return p.detach()
+        sh = self._shadow.get(name)
+        if sh is None or sh.shape != p.shape:
+            sh = torch.empty(p.shape, dtype=torch.bfloat16, device=self.dev)
+            self._shadow[name] = sh
+            self._shadow_ver[name] = None
+        if self._shadow_ver[name] != p._version:
+            ops.cast_bf16(p.detach(), sh)
+            self._shadow_ver[name] = p._version
+        return sh
+
+    def shadow_for_adam(self, name):
+        return self._shadow.get(name) if self.T != F32 else None
+
+    def as_dtype(self, key, t, dtype):
+        """Operand view of an fp32 activation in `dtype` (a bf16 copy when the consumer GEMM is gene-width)."""
+        if t.dtype == dtype:
+            return t
+        out = self.buf(key, t.shape, dtype)
+        ops.prep_input(t, out, False)
+        return out
+
+    # ------------------------------------------------------------------ helpers
+    def _linear_slabs(self, key, a, wname, B):
+        w = self.weight(wname)
+        N, K = w.shape
+        tiles = ((B + 127) // 128) * ((N + 127) // 128)
+        ns = ops.pick_nslab(tiles, K)
+        y = self.buf(key + ".Y", (ns, B, N))
+        ops.linear_fwd(a, w, y, nslab=ns)
+        return y
+
+    def _block_fwd(self, blk, a, cond, masks, train, save):
+        B = a.shape[0]
+        y = self._linear_slabs(blk.name, a, blk.w, B)
+        H = y.shape[2]
+        act = self.buf(blk.name + ".act", (B, H), blk.out_t)
+        yhat = self.buf(blk.name + ".yhat", (B, H)) if save else None
+        rstd = self.buf(blk.name + ".rstd", (B,)) if save else None
+        p = self.cfg["dr_rate"]
+        mask = masks.get(blk.drop_name) if (train and p > 0) else None
+        ops.epilogue_fwd(y, self.p[blk.b].detach() if blk.b else None, cond if blk.use_cond else None,
+                         self.p[blk.wc].detach() if blk.wc else None, mask, p if mask is not None else 0.0,
+                         self.cfg["use_ln"], act, yhat, rstd)
+        return act
+
+    def _block_bwd(self, blk, dact, a_in, cond, masks, need_da, out_slabs=None, extra=None, extra_scale=None):
+        """dact: fp32 [B,H] or slabs.  Returns the slabs of d(a_in) (or None)."""
+        B = a_in.shape[0]
+        H = self.p[blk.w].shape[0]
+        p = self.cfg["dr_rate"]
+        mask = masks.get(blk.drop_name) if p > 0 else None
+        dh = self.buf(blk.name + ".dh", (B, H), blk.gt)
+        ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"], self._ws[blk.name + ".yhat"],
+                         self._ws[blk.name + ".rstd"], dh, extra=extra, extra_scale=extra_scale)
+        if self.p[blk.w].requires_grad:
+            ops.linear_wgrad(dh, a_in, self.gbuf(blk.w))
+        need_b = blk.b is not None and self.p[blk.b].requires_grad
+        need_c = blk.wc is not None and self.p[blk.wc].requires_grad
+        if need_b or need_c:
+            C = cond.shape[1] if need_c else 0
+            ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
+            ops.bias_cond_grad(dh, cond if need_c else None, self.gbuf(blk.b) if need_b else None,
+                               self.gbuf(blk.wc) if need_c else None, ws)
+        if not need_da:
+            return None
+        w = self.weight(blk.w)
+        K = w.shape[1]
+        if out_slabs is None:
+            tiles = ((B + 127) // 128) * ((K + 127) // 128)
+            ns = ops.pick_nslab(tiles, H)
+            out_slabs = self.buf(blk.name + ".da", (ns, B, K))
+        ops.linear_dgrad(dh, w, out_slabs, nslab=out_slabs.shape[0])
+        return out_slabs
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, eps, masks, train=True, save=True, classes_given=True):
+        """batch: dict of device tensors x [B,G] f32, batch [B,C] i64, sizefactor [B] f32, goodloc [B,G] bool,
+        classes [B,P] i64 or None.  Returns a fp32 [4] tensor (recon, kl, mmd, class_ce); leaves everything the
+        backward needs in the workspace."""
+        cfg = self.cfg
+        x = batch["x"]
+        cond = batch.get("batch")
+        B, G = x.shape
+        Bn = B * self.world_size
+        inv_B = 1.0 / Bn
+        self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
+        losses = self.buf("losses", (4,))
+        losses.zero_()
+        status = self.buf("status", (2,), torch.int32)
+        status.zero_()
+        log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
+        xt = self.enc[0].gt
+        if log_in or xt != F32:
+            xin = self.buf("xin", (B, G), xt)
+            pre = batch.get("xin")  # already produced by the device-resident gather
+            if pre is not None and pre.dtype == xt:
+                xin = pre
+            else:
+                ops.prep_input(x, xin, log_in)
+        else:
+            xin = x
+        self._xin = xin
+        # ---- encoder
+        a = xin
+        self._enc_in = []
+        for blk in self.enc:
+            self._enc_in.append(a)
+            a = self._block_fwd(blk, a, cond, masks, train, save)
+        self._henc = a
+        L = cfg["latent"]
+        mulv = self.buf("mulv", (2, B, L))
+        ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
+                       bias=self.p["encoder.mean_encoder.bias"].detach())
+        ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
+                       bias=self.p["encoder.log_var_encoder.bias"].detach())
+        z32 = self.buf("z32", (B, L))
+        red_ws = self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),))
+        zdt = self.dec[0].gt
+        zt = self.buf("zt", (B, L), zdt) if zdt != F32 else z32
+        ops.reparam_kl_fwd(mulv[0], mulv[1], eps, inv_B, cfg["use_own_kl"], z32, zt if zdt != F32 else None,
+                           losses[1:2], red_ws)
+        # ---- decoder
+        d = zt
+        self._dec_in = []
+        for blk in self.dec:
+            self._dec_in.append(d)
+            d = self._block_fwd(blk, d, cond, masks, train, save)
+        self._dlast = d
+        y1 = self._ws["dec0.act"]
+        logits = self.buf("logits", (B, G))
+        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach())
+        # ---- reconstruction loss (+ its unit-upstream gradient)
+        dlogits = self.buf("dlogits", (B, G), self.head_t)
+        if cfg["recon_loss"] == "nb":
+            C = cfg["n_conditions"]
+            ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
+            ops.recon_nb(logits, x, batch["goodloc"], batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
+                         losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1])
+        elif cfg["recon_loss"] == "mse":
+            ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws)
+        else:
+            raise NotImplementedError("recon_loss='zinb' is not built yet (SURVEY.md 8(f) rank 3)")
+        # ---- classifier
+        classes = batch.get("classes")
+        self._has_cls = classes is not None
+        if self._has_cls:
+            c = self.as_dtype("z.cls", z32, self.cls[0].gt)
+            self._cls_in = []
+            for blk in self.cls:
+                self._cls_in.append(c)
+                c = self._block_fwd(blk, c, None, masks, train, save)
+            self._clast = c
+            P = cfg["n_predictors"]
+            if P > 0:
+                u = self.buf("u", (B, P))
+                ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
+                               bias=self.p["classifier.classifier.0.bias"].detach())
+                du = self.buf("du", (B, P), self.gemm_dtype("classifier.classifier.0.weight"))
+                ops.classifier_loss(u, classes, cfg["betaclass"], losses[3:4], du, red_ws)
+        # ---- MMD over the (global) batch
+        self._dfeat = None
+        if cfg["use_mmd"]:
+            feat = z32 if cfg["mmd_on"] == "z" else y1
+            D = feat.shape[1]
+            if self.comm is not None and self.world_size > 1:
+                feat_all, cond_all = self.comm.allgather_rows(feat, cond)
+                row0 = self.rank * B
+            else:
+                feat_all, cond_all, row0 = feat, cond, 0
+            Bg = feat_all.shape[0]
+            part = self.buf("mmd.part", (Bg,), torch.int32)
+            wt = self.buf("mmd.wt", (64 * 64,))
+            pws = self.buf("mmd.pws", (int(ops.lib.c2_partition_ws(Bg)),), torch.uint8)
+            ops.partition(cond_all, cfg["n_conditions"], cfg["main_dataset"], cfg["mmd_boundary"], part, wt, pws,
+                          status[1:2])
+            dfeat = self.buf("mmd.dfeat", (B, D))
+            ws = self.buf("mmd.ws", (ops.mmd_ws(B, Bg, D),))
+            ops.mmd(feat_all, part, wt, row0, B, cfg["beta"], losses[2:3], dfeat, ws)
+            self._dfeat = dfeat
+        return losses
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, g):
+        """g: fp32 device tensor [4] = upstream gradients of (recon, kl, mmd, class_ce).
+        Fills self.grad[name] for every parameter with requires_grad and returns that dict."""
+        cfg = self.cfg
+        B, cond, masks = self._B, self._cond, self._masks
+        gr, gk, gm, gc = g[0:1], g[1:2], g[2:3], g[3:4]
+        rq = lambda n: self.p[n].requires_grad  # noqa: E731
+        dlogits = self._ws["dlogits"]
+        G = dlogits.shape[1]
+        # ---- decoder output layer
+        hw, hb = self.head + ".weight", self.head + ".bias"
+        if rq(hw):
+            ops.linear_wgrad(dlogits, self._dlast, self.gbuf(hw), alpha=gr)
+        if rq(hb):
+            ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+            ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
+        w = self.weight(hw)
+        H1 = w.shape[1]
+        tiles = ((B + 127) // 128) * ((H1 + 127) // 128)
+        ns = ops.pick_nslab(tiles, G)
+        dd = self.buf("dhead.da", (ns, B, H1))
+        ops.linear_dgrad(dlogits, w, dd, nslab=ns, alpha=gr)
+        if cfg["recon_loss"] == "nb" and rq("theta"):
+            gt = self.gbuf("theta")
+            gt.zero_()
+            ops.axpy(self._ws["dtheta.unit"], gr, gt)
+        # ---- decoder hidden blocks, then the first block (mmd_on='y' enters at its output)
+        L = cfg["latent"]
+        n_cls_slab = 1 if (self._has_cls and cfg["n_predictors"] > 0) else 0
+        for i in range(len(self.dec) - 1, 0, -1):
+            dd = self._block_bwd(self.dec[i], dd, self._dec_in[i], cond, masks, True)
+        dz_all = self.buf("dz.all", (1 + n_cls_slab, B, L))
+        on_y = cfg["use_mmd"] and cfg["mmd_on"] != "z"
+        self._block_bwd(self.dec[0], dd, self._dec_in[0], cond, masks, True, out_slabs=dz_all[0:1],
+                        extra=self._dfeat if on_y else None, extra_scale=gm if on_y else None)
+        # ---- classifier branch
+        if n_cls_slab:
+            du = self._ws["du"]
+            cw, cb = "classifier.classifier.0.weight", "classifier.classifier.0.bias"
+            if rq(cw):
+                ops.linear_wgrad(du, self._clast, self.gbuf(cw), alpha=gc)
+            if rq(cb):
+                ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
+                ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
+            dc = self.buf("dcls.da", (1, B, self._clast.shape[1]))
+            ops.linear_dgrad(du, self.weight(cw), dc, alpha=gc)
+            for i in range(len(self.cls) - 1, 0, -1):
+                dc = self._block_bwd(self.cls[i], dc, self._cls_in[i], None, masks, True)
+            self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[1:2])
+        # ---- reparameterisation + KL
+        on_z = cfg["use_mmd"] and cfg["mmd_on"] == "z"
+        mulv = self._ws["mulv"]
+        dml = self.buf("dmulv", (2, B, L), self.gemm_dtype("encoder.mean_encoder.weight"))
+        ops.reparam_kl_bwd(dz_all, mulv[0], mulv[1], self._eps, 1.0 / (B * self.world_size), cfg["use_own_kl"], gk,
+                           dml[0], dml[1], extra=self._dfeat if on_z else None, extra_scale=gm if on_z else None)
+        henc = self._henc
+        Hk = henc.shape[1]
+        da = self.buf("dheads.da", (2, B, Hk))
+        for k, nm in enumerate(("encoder.mean_encoder", "encoder.log_var_encoder")):
+            if rq(nm + ".weight"):
+                ops.linear_wgrad(dml[k], henc, self.gbuf(nm + ".weight"))
+            if rq(nm + ".bias"):
+                ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
+                ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
+            ops.linear_dgrad(dml[k], self.weight(nm + ".weight"), da[k:k + 1])
+        # ---- encoder blocks
+        need = self._first_trainable_enc()
+        for i in range(len(self.enc) - 1, -1, -1):
+            if i < need:
+                break
+            da = self._block_bwd(self.enc[i], da, self._enc_in[i], cond, masks, need_da=(i > need))
+        return {n: gbuf for n, gbuf in self.grad.items() if self.p[n].requires_grad}
+
+    def _first_trainable_enc(self):
+        for i, blk in enumerate(self.enc):
+            names = [blk.w] + ([blk.b] if blk.b else []) + ([blk.wc] if blk.wc else [])
+            if any(self.p[n].requires_grad for n in names):
+                return i
+        return len(self.enc)
+
+    # ------------------------------------------------------------------ inference pieces
+    def encode(self, x, cond, eps=None):
+        """Forward-only encoder: returns (mu, logvar, z) fp32 (celligner2.py:376-409)."""
+        cfg = self.cfg
+        B, G = x.shape
+        if cfg["applylog"] or self.enc[0].gt != F32:
+            xin = self.buf("xin", (B, G), self.enc[0].gt)
+            ops.prep_input(x, xin, cfg["applylog"])  # get_latent applies the log for every recon loss (:398-399)
+        else:
+            xin = x
+        a = xin
+        for blk in self.enc:
+            a = self._block_fwd(blk, a, cond, {}, False, False)
+        L = cfg["latent"]
+        mulv = self.buf("mulv", (2, B, L))
+        ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
+                       bias=self.p["encoder.mean_encoder.bias"].detach())
+        ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
+                       bias=self.p["encoder.log_var_encoder.bias"].detach())
+        z = None
+        if eps is not None:
+            z = self.buf("z32", (B, L))
+            scratch = self.buf("losses.scratch", (1,))
+            scratch.zero_()
+            ops.reparam_kl_fwd(mulv[0], mulv[1], eps, 1.0 / B, cfg["use_own_kl"], z, None, scratch,
+                               self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),)))
+        return mulv[0], mulv[1], z
+
+    def classify(self, z):
+        c = self.as_dtype("z.cls", z, self.cls[0].gt)
+        for blk in self.cls:
+            c = self._block_fwd(blk, c, None, {}, False, False)
+        P = self.cfg["n_predictors"]
+        u = self.buf("u", (z.shape[0], P))
+        if P > 0:
+            ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
+                           bias=self.p["classifier.classifier.0.bias"].detach())
+        return u
+
+    def decode(self, z, cond):
+        """Forward-only decoder (celligner2.py:411-420): returns (output, y1) like Decoder.forward."""
+        d = self.as_dtype("z.dec", z, self.dec[0].gt)
+        for blk in self.dec:
+            d = self._block_fwd(blk, d, cond, {}, False, False)
+        B = z.shape[0]
+        G = self.cfg["input_dim"]
+        logits = self.buf("logits", (B, G))
+        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach())
+        return logits, self._ws["dec0.act"]
+
+    def check_status(self):
+        """Host sync: raise where the reference would have raised."""
+        st = self._ws.get("status")
+        if st is None:
+            return
+        s = st.tolist()
+        if s[0]:
+            raise IndexError("condition values outside {0,1} reached the NB dispersion one-hot "
+                             "(the reference's scatter_ raises 'index out of range' here)")
+        if s[1]:
+            raise RuntimeError("MMD partition: unsupported condition rows (values outside {0,1}, more than 64 "
+                               "distinct rows, an empty main dataset or fewer partitions than mmd_boundary needs)")

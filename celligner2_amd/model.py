@@ -1,0 +1,390 @@
+"""Drop-in `Celligner2` module (mirror of celligner2/model/celligner2.py:15-420 in the reference).
+
+Same constructor signature (positional order included), same sub-module tree and state_dict
+keys/shapes, same `forward(x, batch, sizefactor, classes, weight, goodloc, main_dataset)` ->
+`(recon_loss, kl_div, mmd_loss, class_ce_loss)` 0-d tensors that support `+`, `.item()` and
+`.backward()`.  Every operation behind it runs in the HIP library (engine.StepEngine): the
+sub-modules below only own parameters and give the tree its reference shape.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import StepEngine
+
+
+# ------------------------------------------------------------------ parameter-holding tree
+class _Linear(nn.Linear):
+    """nn.Linear used as a parameter holder (same init, same RNG consumption as the reference)."""
+
+    def forward(self, inp):  # pragma: no cover - the model never calls sub-modules
+        raise RuntimeError("celligner2_amd sub-modules hold parameters only; call the Celligner2 module")
+
+
+class _Marker(nn.Module):
+    """Parameter-free stand-in for LayerNorm / ReLU / Dropout / Softmax entries of the reference tree."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+
+class CondLayers(nn.Module):  # modules.py:39-130 (MaskedCondLayers / CondLayers)
+    def __init__(self, n_in, n_out, n_cond, bias):
+        super().__init__()
+        self.n_cond = n_cond
+        self.expr_L = _Linear(n_in, n_out, bias=bias)
+        if n_cond != 0:
+            self.cond_L = _Linear(n_cond, n_out, bias=False)
+
+
+def _norm_act_drop(seq, i, size, use_bn, use_ln, use_dr, dr_rate):
+    if use_bn:
+        raise NotImplementedError("use_bn=True (BatchNorm1d) is not built yet (SURVEY.md 8(f) rank 3)")
+    if use_ln:
+        seq.add_module(f"N{i}", _Marker(f"LayerNorm({size}, elementwise_affine=False)"))
+    seq.add_module(f"A{i}", _Marker("ReLU"))
+    if use_dr:
+        seq.add_module(f"D{i}", _Marker(f"Dropout(p={dr_rate})"))
+
+
+class Encoder(nn.Module):  # modules.py:228-332
+    def __init__(self, layer_sizes, latent_dim, use_bn, use_ln, use_dr, dr_rate, num_classes=0):
+        super().__init__()
+        self.n_classes = num_classes
+        self.FC = nn.Sequential()
+        for i, (a, b) in enumerate(zip(layer_sizes[:-1], layer_sizes[1:])):
+            if i == 0:
+                self.FC.add_module("L0", CondLayers(a, b, num_classes, bias=True))
+            else:
+                self.FC.add_module(f"L{i}", _Linear(a, b, bias=True))
+            _norm_act_drop(self.FC, i, b, use_bn, use_ln, use_dr, dr_rate)
+        self.mean_encoder = _Linear(layer_sizes[-1], latent_dim)
+        self.log_var_encoder = _Linear(layer_sizes[-1], latent_dim)
+
+
+class Decoder(nn.Module):  # modules.py:335-513
+    def __init__(self, layer_sizes, latent_dim, recon_loss, use_bn, use_ln, use_dr, dr_rate, num_classes=0):
+        super().__init__()
+        self.recon_loss = recon_loss
+        self.n_classes = num_classes
+        ls = [latent_dim] + layer_sizes
+        self.FirstL = nn.Sequential()
+        self.FirstL.add_module("L0", CondLayers(ls[0], ls[1], num_classes, bias=False))
+        _norm_act_drop(self.FirstL, 0, ls[1], use_bn, use_ln, use_dr, dr_rate)
+        self.HiddenL = nn.Sequential()
+        for i, (a, b) in enumerate(zip(ls[1:-1], ls[2:])):
+            if i + 3 < len(ls):
+                self.HiddenL.add_module(f"L{i + 1}", _Linear(a, b, bias=False))
+                _norm_act_drop(self.HiddenL, i + 1, b, use_bn, use_ln, use_dr, dr_rate)
+        if recon_loss == "mse":
+            self.recon_decoder = nn.Sequential(_Linear(ls[-2], ls[-1]), _Marker("ReLU"))
+        elif recon_loss == "nb":
+            self.mean_decoder = nn.Sequential(_Linear(ls[-2], ls[-1]), _Marker("Softmax(dim=-1)"))
+        else:
+            raise NotImplementedError("recon_loss='zinb' is not built yet (SURVEY.md 8(f) rank 3)")
+
+
+class Classifier(nn.Module):  # modules.py:516-633
+    def __init__(self, layer_sizes, latent_dim, dr_rate, use_bn, use_ln, use_dr, num_classes=0):
+        super().__init__()
+        self.n_classes = num_classes
+        ls = [latent_dim] + layer_sizes + [num_classes]
+        self.FirstL = nn.Sequential()
+        self.FirstL.add_module("L0", _Linear(ls[0], ls[1], bias=False))
+        _norm_act_drop(self.FirstL, 0, ls[1], use_bn, use_ln, use_dr, dr_rate)
+        if len(ls) > 3:
+            self.HiddenL = nn.Sequential()
+            for i, (a, b) in enumerate(zip(ls[1:-2], ls[2:-1])):
+                self.HiddenL.add_module(f"L{i + 1}", _Linear(a, b, bias=False))
+                _norm_act_drop(self.HiddenL, i + 1, b, use_bn, use_ln, use_dr, dr_rate)
+        else:
+            self.HiddenL = None
+        self.classifier = nn.Sequential(_Linear(ls[-2], ls[-1]))
+
+
+# ------------------------------------------------------------------ autograd bridge
+class _StepFn(torch.autograd.Function):
+    """The four losses as one autograd node: forward and the unit-upstream loss gradients are computed by the
+    engine in the forward pass, `backward` runs the engine's backward chain with the incoming (device) scalars."""
+
+    @staticmethod
+    def forward(ctx, model, batch, eps, masks, *params):
+        eng = model._engine()
+        losses = eng.forward(batch, eps, masks, train=model.training, save=True)
+        ctx.model = model
+        out = losses.clone()
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        model = ctx.model
+        eng = model._engine()
+        g = torch.stack([gi if gi is not None else torch.zeros((), device=eng.dev) for gi in (g0, g1, g2, g3)]).float()
+        grads = eng.backward(g)
+        names = model._param_names
+        params = model._param_list
+        if all(p.grad is None for p in params):
+            # hand the engine's persistent gradient buffers over without a copy
+            for n, p in zip(names, params):
+                if p.requires_grad and n in grads:
+                    p.grad = grads[n]
+            return (None, None, None, None) + tuple(None for _ in params)
+        return (None, None, None, None) + tuple(
+            (grads[n].clone() if (p.requires_grad and n in grads) else None) for n, p in zip(names, params))
+
+
+class Celligner2(nn.Module):
+    def __init__(
+        self,
+        input_dim: int,
+        hidden_layer_sizes: list = [256, 64],
+        latent_dim: int = 10,
+        dr_rate: float = 0.05,
+        use_own_kl: bool = False,
+        recon_loss: Optional[str] = "nb",
+        use_bn: bool = False,
+        use_ln: bool = True,
+        applylog: bool = True,
+        # conditional part
+        conditions: list = [],
+        use_mmd: bool = False,
+        mmd_on: str = "z",
+        mmd_boundary: Optional[int] = None,
+        beta: float = 1,
+        main_dataset: str = None,
+        batch_knowledge: bool = True,
+        # classifier part
+        predictors: list = [],
+        classifier_hidden_layer_sizes: list = [32],
+        betaclass: float = 0.8,
+        # GNN part
+        graph_layers: int = 0,
+        res_mult: int = 0,
+        # expimap part
+        n_expand: int = 0,
+        expimap_mode: bool = None,
+        mask: Optional[Union[np.ndarray, list]] = None,
+        ext_mask: Optional[Union[np.ndarray, list]] = None,
+        n_unconstrained: int = 0,
+        ext_n_unconstrained: int = 0,
+        use_l_encoder: bool = False,
+        use_hsic: bool = False,
+        hsic_one_vs_all: bool = False,
+        # MI355X build only
+        precision: str = "fp32",
+    ):
+        super().__init__()
+        assert isinstance(hidden_layer_sizes, list)
+        assert isinstance(latent_dim, int)
+        assert isinstance(conditions, list)
+        assert recon_loss in ["mse", "nb", "zinb"], "'recon_loss' must be 'mse', 'nb' or 'zinb'"
+        assert precision in ("fp32", "bf16")
+        if len(hidden_layer_sizes) < 2:
+            raise TypeError("hidden_layer_sizes needs >= 2 entries (the reference decoder fails otherwise: "
+                            "celligner2/model/modules.py:434-435,498-499)")
+        for flag, nm in ((n_expand, "n_expand"), (expimap_mode, "expimap_mode"), (mask is not None, "mask"),
+                         (ext_mask is not None, "ext_mask"), (use_l_encoder, "use_l_encoder"), (use_hsic, "use_hsic"),
+                         (graph_layers, "graph_layers")):
+            if flag:
+                raise NotImplementedError(f"{nm} belongs to the reference's unfinished expimap/GNN branches "
+                                          "(README.md:31-43) and is outside the accelerated path")
+        if not batch_knowledge:
+            raise NotImplementedError("batch_knowledge=False is outside the accelerated path")
+        self.input_dim = input_dim
+        self.latent_dim = latent_dim
+        self.n_predictors = len(predictors)
+        self.n_conditions = len(conditions)
+        self.use_own_kl = use_own_kl
+        self.conditions = conditions
+        self.predictors = predictors
+        self.applylog = applylog
+        self.condition_encoder = {k: v for k, v in zip(conditions, range(len(conditions)))}
+        self.predictor_encoder = {k: v for k, v in zip(predictors, range(len(predictors)))}
+        self.use_hsic = False
+        self.hsic_one_vs_all = hsic_one_vs_all
+        self.n_unconstrained = n_unconstrained
+        self.use_l_encoder = use_l_encoder
+        self.cell_type_encoder = None
+        self.recon_loss = recon_loss
+        self.mmd_boundary = mmd_boundary
+        self.use_mmd = use_mmd
+        self.freeze = False
+        self.beta = beta
+        self.betaclass = betaclass
+        self.use_bn = use_bn
+        self.use_ln = use_ln
+        self.mmd_on = mmd_on
+        self.main_dataset = main_dataset
+        self.batch_knowledge = batch_knowledge
+        self.res_mult = res_mult
+        self.graph_layers = graph_layers
+        self.dr_rate = dr_rate
+        self.use_dr = self.dr_rate > 0
+        self.precision = precision
+        self.rng_mode = "device"  # "reference": draw eps/dropout on torch's CPU generator in the reference's order
+        self._forced_noise = None
+        self.mask = None
+        self.ext_mask = None
+        self.n_expand = n_expand
+        # creation order == the reference's (same seed -> same initial weights)
+        if recon_loss in ["nb", "zinb"]:
+            self.theta = torch.nn.Parameter(torch.randn(self.input_dim, self.n_conditions))
+        else:
+            self.theta = None
+        self.hidden_layer_sizes = hidden_layer_sizes
+        enc_sizes = [self.input_dim] + list(hidden_layer_sizes)
+        dec_sizes = list(hidden_layer_sizes)[::-1] + [self.input_dim]
+        self.classifier_hidden_layer_sizes = classifier_hidden_layer_sizes
+        self.encoder = Encoder(enc_sizes, latent_dim, use_bn, use_ln, self.use_dr, dr_rate, self.n_conditions)
+        self.classifier = Classifier(list(classifier_hidden_layer_sizes), latent_dim, dr_rate, use_bn, use_ln,
+                                     self.use_dr, self.n_predictors)
+        self.decoder = Decoder(dec_sizes, latent_dim, recon_loss, use_bn, use_ln, self.use_dr, dr_rate,
+                               self.n_conditions)
+        self.__dict__["_eng"] = None
+        self.world = None  # parallel.DataParallelStep attaches itself here
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _cfg(self):
+        return dict(
+            input_dim=self.input_dim, hidden=list(self.hidden_layer_sizes), latent=self.latent_dim,
+            n_conditions=self.n_conditions, n_predictors=self.n_predictors,
+            cls_hidden=list(self.classifier_hidden_layer_sizes), recon_loss=self.recon_loss, dr_rate=float(self.dr_rate),
+            use_own_kl=bool(self.use_own_kl), applylog=bool(self.applylog), use_mmd=bool(self.use_mmd),
+            mmd_on=self.mmd_on, mmd_boundary=self.mmd_boundary, beta=float(self.beta),
+            main_dataset=(self.condition_encoder[self.main_dataset] if self.main_dataset else None),
+            betaclass=float(self.betaclass), use_ln=bool(self.use_ln))
+
+    def _engine(self) -> StepEngine:
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        if dev.type != "cuda":
+            raise ops.L.C2Error("celligner2_amd.Celligner2 computes only on an MI355X: move the module to the GPU "
+                                "(model.cuda()); there is no CPU path")
+        eng = self.__dict__["_eng"]
+        cfg = self._cfg()
+        stale = (eng is None or eng.dev != dev or eng.cfg != cfg or eng.precision != self.precision
+                 or any(eng.p.get(n) is not p for n, p in params.items()) or len(eng.p) != len(params))
+        if stale:
+            eng = StepEngine(cfg, params, self.precision)
+            if self.world is not None:
+                self.world.attach(eng)
+            self.__dict__["_eng"] = eng
+        self.__dict__["_param_names"] = list(params.keys())
+        self.__dict__["_param_list"] = list(params.values())
+        return eng
+
+    def _dropout_shapes(self, B):
+        out = []
+        if self.use_dr:
+            hs = list(self.hidden_layer_sizes)
+            out += [(f"enc.D{i}", (B, h)) for i, h in enumerate(hs)]
+            out += [(f"dec.D{i}", (B, h)) for i, h in enumerate(hs[::-1])]
+        return out
+
+    def _draw_noise(self, B, with_classes, device):
+        """eps [B,L] and the dropout keep-masks, in the reference's RNG consumption order
+        (SURVEY.md Appendix A.9): encoder dropouts, eps, decoder dropouts, classifier dropouts."""
+        if self._forced_noise is not None:
+            fn = self._forced_noise
+            return fn["eps"], fn.get("masks", {})
+        shapes = self._dropout_shapes(B)
+        nh = len(self.hidden_layer_sizes)
+        cls_shapes = []
+        if self.use_dr and with_classes:
+            cls_shapes = [(f"cls.D{i}", (B, h)) for i, h in enumerate(self.classifier_hidden_layer_sizes)]
+        training = self.training
+        masks = {}
+        if self.rng_mode == "reference":
+            def cpu_mask(shape):
+                m = torch.nn.functional.dropout(torch.ones(shape), self.dr_rate, True)
+                return (m != 0).to(torch.uint8).to(device)
+            if training:
+                for n, s in shapes[:nh]:
+                    masks[n] = cpu_mask(s)
+            eps = torch.empty(B, self.latent_dim).normal_().to(device)
+            if training:
+                for n, s in shapes[nh:] + cls_shapes:
+                    masks[n] = cpu_mask(s)
+        else:
+            if training:
+                for n, s in shapes[:nh]:
+                    masks[n] = (torch.rand(s, device=device) >= self.dr_rate).to(torch.uint8)
+            eps = torch.randn(B, self.latent_dim, device=device)
+            if training:
+                for n, s in shapes[nh:] + cls_shapes:
+                    masks[n] = (torch.rand(s, device=device) >= self.dr_rate).to(torch.uint8)
+        return eps, masks
+
+    # ------------------------------------------------------------------ the reference's API
+    def forward(self, x=None, batch=None, sizefactor=None, classes=None, weight=None, goodloc=None,
+                main_dataset=None, xin=None):
+        dev = x.device
+        B = x.shape[0]
+        x = x.float().contiguous()
+        if goodloc is None:
+            goodloc = torch.ones_like(x, dtype=torch.bool)
+        if sizefactor is None:
+            sizefactor = x.sum(1)
+        bt = dict(x=x, goodloc=goodloc.contiguous(), sizefactor=sizefactor.reshape(B).float().contiguous())
+        if batch is not None:
+            bt["batch"] = batch.long().contiguous()
+        elif self.n_conditions:
+            raise ValueError("the model has conditions but no `batch` tensor was given")
+        if classes is not None:
+            if classes.dtype != torch.int64 or not classes.is_contiguous():
+                raise TypeError("classes must be a contiguous int64 tensor (it is modified in place, as the "
+                                "reference does: celligner2/model/losses.py:324-325)")
+            bt["classes"] = classes
+        if xin is not None:
+            bt["xin"] = xin
+        eps, masks = self._draw_noise(B, classes is not None, dev)
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._engine()
+            return _StepFn.apply(self, bt, eps, masks, *params)
+        eng = self._engine()
+        losses = eng.forward(bt, eps, masks, train=self.training, save=False).clone()
+        return losses[0], losses[1], losses[2], losses[3]
+
+    def sampling(self, mu, log_var):
+        """othermodels/base/_base.py:464-480."""
+        eps = torch.randn_like(mu)
+        return mu + torch.sqrt(torch.exp(log_var) + 1e-4) * eps
+
+    @torch.no_grad()
+    def get_latent(self, x, c=None, mean=False, add_classpred=False):
+        """celligner2.py:376-409: encoder (+ sampling) (+ classifier on z_mean)."""
+        eng = self._engine()
+        x = x.float().contiguous()
+        B = x.shape[0]
+        if self._forced_noise is not None:
+            eps = self._forced_noise["eps"]
+        elif self.rng_mode == "reference":
+            eps = torch.empty(B, self.latent_dim).normal_().to(x.device)
+        else:
+            eps = torch.randn(B, self.latent_dim, device=x.device)
+        mu, lv, z = eng.encode(x, c.long().contiguous() if c is not None else None, eps)
+        mu = mu.clone()
+        classes = eng.classify(mu).clone() if add_classpred else None
+        if mean:
+            return (mu, classes)
+        return (z.clone(), classes)
+
+    @torch.no_grad()
+    def reconstructLatent(self, latent, c=None):
+        """celligner2.py:411-420: decoder output (softmax means for nb, ReLU output for mse) and y1."""
+        eng = self._engine()
+        latent = torch.as_tensor(latent, device=next(self.parameters()).device).float().contiguous()
+        logits, y1 = eng.decode(latent, c.long().contiguous() if c is not None else None)
+        if self.recon_loss == "mse":
+            return torch.relu(logits), y1.float().clone()
+        return torch.softmax(logits, dim=-1), y1.float().clone()

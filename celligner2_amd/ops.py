@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/c2mi.h).
+
+All tensors live on the GPU; shapes/strides are checked here on the host before any
+kernel is enqueued.  Nothing in this module computes on the CPU.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import check, dt_code, lib, ptr, stream
+
+
+def _row_major(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise L.C2Error(f"{name}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    return t.stride(0)
+
+
+def pick_nslab(tiles, R, bk=64, target=512, max_slab=16):
+    """Split a long reduction so that the launch has >= ~2 blocks per CU."""
+    if tiles >= target or R <= 4 * bk:
+        return 1
+    n = min(max_slab, (target + tiles - 1) // tiles, max(1, R // (4 * bk)))
+    return max(1, n)
+
+
+def prep_input(x, out, apply_log):
+    L.require_gpu(x, out)
+    check(lib.c2_prep_input(ptr(x), x.shape[0], x.shape[1], _row_major(x, "x"), ptr(out), dt_code(out.dtype),
+                            _row_major(out, "out"), int(apply_log), stream()))
+    return out
+
+
+def linear_fwd(a, w, y, bias=None, nslab=1):
+    """y[s] = a @ w.T (+bias).  y: [M,N] or [nslab,M,N] fp32."""
+    L.require_gpu(a, w, y)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype and y.dtype == torch.float32
+    y2 = y if y.dim() == 2 else y[0]
+    assert tuple(y2.shape) == (M, N)
+    ss = y.stride(0) if y.dim() == 3 else 0
+    assert (y.dim() == 3 and y.shape[0] == nslab) or nslab == 1
+    check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), dt_code(a.dtype), M, N, K, ptr(y),
+                            _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
+    return y
+
+
+def linear_dgrad(dy, w, da, nslab=1, alpha=None):
+    """da[s] = alpha * dy @ w.   dy [M,N], w [N,K], da [M,K] or [nslab,M,K]."""
+    L.require_gpu(dy, w, da)
+    M, N = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == N and dy.dtype == w.dtype and da.dtype == torch.float32
+    d2 = da if da.dim() == 2 else da[0]
+    assert tuple(d2.shape) == (M, K)
+    ss = da.stride(0) if da.dim() == 3 else 0
+    assert (da.dim() == 3 and da.shape[0] == nslab) or nslab == 1
+    check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), dt_code(dy.dtype), M, N, K,
+                              ptr(da), _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
+    return da
+
+
+def linear_wgrad(dy, a, dw, nslab=1, alpha=None):
+    """dw[s] = alpha * dy.T @ a.   dy [M,N], a [M,K], dw [N,K] or [nslab,N,K]."""
+    L.require_gpu(dy, a, dw)
+    M, N = dy.shape
+    K = a.shape[1]
+    assert a.shape[0] == M and dy.dtype == a.dtype and dw.dtype == torch.float32
+    d2 = dw if dw.dim() == 2 else dw[0]
+    assert tuple(d2.shape) == (N, K)
+    ss = dw.stride(0) if dw.dim() == 3 else 0
+    assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
+    check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), dt_code(dy.dtype), M, N, K,
+                              ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
+    return dw
+
+
+def sum_slabs(slabs, out):
+    n = out.numel()
+    assert slabs.is_contiguous() and out.is_contiguous() and slabs.numel() == slabs.shape[0] * n
+    check(lib.c2_sum_slabs(ptr(slabs), slabs.shape[0], n, ptr(out), n, stream()))
+    return out
+
+
+def _slabs(y):
+    """(ptr-tensor, ld, nslab, slab_stride, rows, cols) of a [M,N] or [S,M,N] fp32 tensor."""
+    if y.dim() == 3:
+        return y, y.stride(1), y.shape[0], y.stride(0), y.shape[1], y.shape[2]
+    return y, y.stride(0), 1, 0, y.shape[0], y.shape[1]
+
+
+def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=None):
+    L.require_gpu(y, act)
+    yt, ldy, ns, ss, B, H = _slabs(y)
+    assert y.dtype == torch.float32 and tuple(act.shape) == (B, H)
+    C = 0
+    if cond is not None and wc is not None:
+        assert cond.dtype == torch.int64 and cond.is_contiguous() and cond.shape[0] == B
+        C = cond.shape[1]
+        assert tuple(wc.shape) == (H, C) and wc.dtype == torch.float32
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (B, H)
+    if yhat is not None:
+        assert yhat.is_contiguous() and tuple(yhat.shape) == (B, H) and yhat.dtype == torch.float32
+    check(lib.c2_epilogue_fwd(ptr(yt), ldy, ns, ss, ptr(bias), ptr(cond) if C else None, C, ptr(wc) if C else None,
+                              wc.stride(0) if C else 0, ptr(mask), float(p_drop), int(use_ln), B, H, ptr(act),
+                              dt_code(act.dtype), _row_major(act, "act"), ptr(yhat), ptr(rstd), stream()))
+    return act
+
+
+def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_scale=None):
+    L.require_gpu(da, dh)
+    dt, ldda, ns, ss, B, H = _slabs(da)
+    assert da.dtype == torch.float32 and tuple(dh.shape) == (B, H) and yhat.is_contiguous()
+    if extra is not None:
+        assert extra.dtype == torch.float32 and tuple(extra.shape) == (B, H)
+    check(lib.c2_epilogue_bwd(ptr(dt), ldda, ns, ss, ptr(extra), extra.stride(0) if extra is not None else 0,
+                              ptr(extra_scale), ptr(mask), float(p_drop), int(use_ln), ptr(yhat), ptr(rstd), B, H,
+                              ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), stream()))
+    return dh
+
+
+def bias_cond_grad_ws(B, H, C):
+    return int(lib.c2_bias_cond_grad_ws(B, H, C))
+
+
+def bias_cond_grad(dh, cond, db, dwc, ws, alpha=None):
+    L.require_gpu(dh, ws)
+    B, H = dh.shape
+    C = cond.shape[1] if (cond is not None and dwc is not None) else 0
+    assert ws.numel() >= bias_cond_grad_ws(B, H, C)
+    if dwc is not None:
+        assert tuple(dwc.shape) == (H, C) and dwc.dtype == torch.float32
+    check(lib.c2_bias_cond_grad(ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), ptr(cond) if C else None, C, B, H,
+                                ptr(db), ptr(dwc) if C else None, dwc.stride(0) if C else 0, ptr(alpha), ptr(ws), stream()))
+
+
+def reparam_kl_fwd(mu, lv, eps, inv_B, use_own_kl, z32, zt, kl_out, ws):
+    L.require_gpu(mu, lv, eps, z32)
+    B, Ld = mu.shape
+    assert mu.stride(0) == lv.stride(0) and eps.is_contiguous() and z32.is_contiguous()
+    check(lib.c2_reparam_kl_fwd(ptr(mu), ptr(lv), ptr(eps), B, Ld, mu.stride(0), float(inv_B), int(use_own_kl), ptr(z32),
+                                ptr(zt), dt_code(zt.dtype) if zt is not None else 0,
+                                zt.stride(0) if zt is not None else 0, ptr(kl_out), ptr(ws), stream()))
+
+
+def reparam_kl_bwd(dz, mu, lv, eps, inv_B, use_own_kl, g_kl, dmu, dlv, extra=None, extra_scale=None):
+    L.require_gpu(dz, mu, dmu)
+    dt, lddz, ns, ss, B, Ld = _slabs(dz)
+    assert dmu.stride(0) == dlv.stride(0) and dmu.dtype == dlv.dtype
+    check(lib.c2_reparam_kl_bwd(ptr(dt), lddz, ns, ss, ptr(extra), extra.stride(0) if extra is not None else 0,
+                                ptr(extra_scale), ptr(mu), ptr(lv), ptr(eps), B, Ld, mu.stride(0), float(inv_B),
+                                int(use_own_kl), ptr(g_kl), ptr(dmu), ptr(dlv), dt_code(dmu.dtype), dmu.stride(0),
+                                stream()))
+
+
+def recon_nb_ws(B, G, C):
+    return int(lib.c2_recon_nb_ws(B, G, C))
+
+
+def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status):
+    L.require_gpu(logits, x, goodloc, dlogits)
+    B, G = x.shape
+    C = theta.shape[1]
+    assert goodloc.dtype in (torch.bool, torch.uint8) and theta.is_contiguous() and cond.is_contiguous()
+    assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
+    assert ws.numel() >= recon_nb_ws(B, G, C) and sizefactor.dtype == torch.float32 and sizefactor.is_contiguous()
+    check(lib.c2_recon_nb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"), ptr(goodloc),
+                                  _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta), ptr(cond), C, B, G,
+                                  float(inv_B), ptr(loss_out), ptr(dlogits), dt_code(dlogits.dtype),
+                                  _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws), ptr(status), stream()))
+
+
+def recon_mse(logits, x, goodloc, inv_B, loss_out, dlogits, ws):
+    L.require_gpu(logits, x, goodloc, dlogits)
+    B, G = x.shape
+    check(lib.c2_recon_mse_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"), ptr(goodloc),
+                                   _row_major(goodloc, "goodloc"), B, G, float(inv_B), ptr(loss_out), ptr(dlogits),
+                                   dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"), ptr(ws), stream()))
+
+
+def classifier_loss(u, classes, betaclass, loss_out, du, ws):
+    L.require_gpu(u, classes, du)
+    B, P = u.shape
+    assert classes.dtype == torch.int64 and classes.is_contiguous() and tuple(classes.shape) == (B, P)
+    check(lib.c2_classifier_loss_fwd_bwd(ptr(u), u.stride(0), ptr(classes), B, P, float(betaclass), ptr(loss_out), ptr(du),
+                                         dt_code(du.dtype), du.stride(0), ptr(ws), stream()))
+
+
+def partition(cond, n_conditions, main_col, boundary, part_id, wt, ws, status):
+    L.require_gpu(cond, part_id, wt)
+    B, C = cond.shape
+    assert cond.dtype == torch.int64 and cond.is_contiguous() and part_id.dtype == torch.int32
+    assert wt.numel() >= L.MMD_MAX_PARTS ** 2 and ws.numel() * ws.element_size() >= int(lib.c2_partition_ws(B))
+    check(lib.c2_partition(ptr(cond), B, C, int(n_conditions), -1 if main_col is None else int(main_col),
+                           -1 if boundary is None else int(boundary), ptr(part_id), ptr(wt), ptr(ws), ptr(status),
+                           stream()))
+
+
+def mmd_ws(Bl, Bg, D):
+    return int(lib.c2_mmd_ws(Bl, Bg, D))
+
+
+def mmd(feat, part_id, wt, row0, Bl, beta, loss_out, dfeat, ws):
+    L.require_gpu(feat, part_id, wt, dfeat)
+    Bg, D = feat.shape
+    assert dfeat.is_contiguous() and tuple(dfeat.shape) == (Bl, D) and ws.numel() >= mmd_ws(Bl, Bg, D)
+    check(lib.c2_mmd_fwd_bwd(ptr(feat), dt_code(feat.dtype), _row_major(feat, "feat"), ptr(part_id), ptr(wt), int(row0),
+                             int(Bl), Bg, D, float(beta), ptr(loss_out), ptr(dfeat), D, ptr(ws), stream()))
+
+
+def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
+    """entries: list of (p, g, m, v, shadow_or_None) contiguous fp32 tensors."""
+    n = len(entries)
+    arr = (L.AdamTensor * max(n, 1))()
+    for i, (p, g, m, v, sh) in enumerate(entries):
+        L.require_gpu(p, g, m, v)
+        assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+        assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and g.numel() == p.numel()
+        if sh is not None:
+            assert sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == p.numel()
+        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel())
+    check(lib.c2_adam_step(arr, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                           float(clip_value), int(step_t), stream()))
+
+
+def cast_bf16(src, dst):
+    L.require_gpu(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    check(lib.c2_cast_bf16(ptr(src), ptr(dst), src.numel(), stream()))
+    return dst
+
+
+def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, sf_out, cond_out, classes_out, xin_out,
+                apply_log):
+    L.require_gpu(X, idx, x_out)
+    G = X.shape[1]
+    n = idx.numel()
+    C = cond.shape[1] if cond is not None else 0
+    P = classes.shape[1] if classes is not None else 0
+    assert X.is_contiguous() and x_out.is_contiguous() and idx.dtype == torch.int64
+    check(lib.c2_gather_rows(ptr(X), ptr(goodloc), ptr(sizefactor), ptr(cond), ptr(classes), G, C, P, ptr(idx), n,
+                             ptr(x_out), ptr(goodloc_out), ptr(sf_out), ptr(cond_out), ptr(classes_out), ptr(xin_out),
+                             dt_code(xin_out.dtype) if xin_out is not None else 0,
+                             xin_out.stride(0) if xin_out is not None else 0, int(apply_log), stream()))
+
+
+def axpy(x, a_dev, y):
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib.c2_axpy(ptr(x), ptr(a_dev), ptr(y), x.numel(), stream()))

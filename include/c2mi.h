@@ -1,0 +1,182 @@
+/*
+ * c2mi.h -- C-ABI of the MI355X (gfx950) Celligner2 training-step library (libc2mi.so).
+ *
+ * The reference (broadinstitute/celligner2) has no FFI: its hot path is Python calling
+ * stock torch ops.  Each entry point below replaces the torch-op sequence of the cited
+ * reference lines (paths relative to the reference root) with hand-written HIP kernels.
+ * The host mirror (celligner2_amd/) binds these with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - matrices are row-major, leading dimensions (ld*) are in ELEMENTS;
+ *   - `dtype` arguments: C2_F32 or C2_BF16 (storage type of GEMM operands / activations);
+ *     accumulation, losses, parameter gradients and optimizer state are always fp32;
+ *   - `stream` is a hipStream_t passed as void*; calls enqueue work and return, they never
+ *     synchronise the device and never allocate device memory (workspaces are caller-owned);
+ *   - return value: 0 = ok, non-zero = error; c2_last_error() returns a thread-local message;
+ *   - "slabs": a split reduction writes `nslab` partial fp32 matrices, slab s at
+ *     base + s*slab_stride elements; consumers take (nslab, slab_stride) and sum them.
+ */
+#ifndef C2MI_H
+#define C2MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2_F32 0
+#define C2_BF16 1
+
+#define C2_MMD_MAX_PARTS 64 /* max distinct condition rows per batch for the MMD partition */
+
+const char* c2_last_error(void);
+int c2_version(void);
+
+/* x_log = log(1 + x) (celligner2/model/celligner2.py:269-274) or a plain copy/convert.
+ * out dtype f32 or bf16.  rows x cols, ldx/ldo in elements. */
+int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* out, int out_dtype,
+                  int64_t ldo, int apply_log, void* stream);
+
+/* nn.Linear forward without the bias/cond/norm tail (modules.py:100,126,296,314-315,443,469,481,617):
+ *   Y[s][m][n] = sum_{k in split s} A[m][k] * W[n][k]      (+ bias[n] when bias != NULL; needs nslab == 1)
+ * A [M,K] and W [N,K] have dtype `dtype`; Y is fp32. */
+int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
+                  int64_t K, float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
+                  void* stream);
+
+/* autograd of the same Linear w.r.t. its input:
+ *   dA[s][m][k] = alpha * sum_{n in split s} dY[m][n] * W[n][k]      alpha = *alpha_dev or 1 */
+int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
+                    int64_t K, float* dA, int64_t ldda, int nslab, int64_t slab_stride,
+                    const float* alpha_dev, void* stream);
+
+/* autograd of the same Linear w.r.t. its weight:
+ *   dW[s][n][k] = alpha * sum_{m in split s} dY[m][n] * A[m][k] */
+int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, int dtype, int64_t M, int64_t N,
+                    int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
+                    const float* alpha_dev, void* stream);
+
+/* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
+int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);
+
+/* Tail of one layer block (modules.py:77-107,124-130 cond add; :298-312 norm/act/dropout):
+ *   h = sum_s Y[s] (+ bias) (+ sum_j cond[b][j] * Wc[:,j]);  LayerNorm(no affine, eps 1e-5, biased var)
+ *   when use_ln; ReLU; dropout (keep-mask u8, scale 1/(1-p)) when mask != NULL.
+ * Writes act (dtype act_dtype) and, for the backward, yhat (fp32, normalised pre-activation) and
+ * rstd (fp32 [B]).  cond is the int64 multi-hot matrix [B,C] (row stride C). */
+int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
+                    const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
+                    float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype, int64_t ldact,
+                    float* yhat, float* rstd, void* stream);
+
+/* Backward of the same tail:  dact = sum_s dA[s] (+ extra_scale * extra); through dropout, ReLU, LayerNorm.
+ * Writes dh (dtype dh_dtype), the gradient w.r.t. the Linear output. */
+int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
+                    int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
+                    int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
+                    int dh_dtype, int64_t lddh, void* stream);
+
+/* Bias / condition-weight gradients of a block (autograd of modules.py:100-106):
+ *   db[h] = alpha * sum_b dh[b][h];   dWc[h][j] = alpha * sum_b dh[b][h] * cond[b][j]
+ * Either output may be NULL.  ws: fp32 workspace of c2_bias_cond_grad_ws(B,H,C) elements. */
+size_t c2_bias_cond_grad_ws(int64_t B, int64_t H, int C);
+int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, const int64_t* cond, int C, int64_t B,
+                      int64_t H, float* db, float* dWc, int64_t lddwc, const float* alpha_dev, float* ws,
+                      void* stream);
+
+/* Reparameterisation + KL (othermodels/base/_base.py:464-480; celligner2.py:311-322):
+ *   v = exp(lv)+1e-4; z = mu + sqrt(v)*eps;  kl (default) = (1/Bn) sum 0.5(v+mu^2-1-log v),
+ *   use_own_kl: -0.5 sum(1+lv-mu^2-v).  inv_B = 1/Bn with Bn the GLOBAL batch rows.
+ * z32 (fp32) and zt (dtype zt_dtype, may be NULL) are written; the KL value is ADDED to *kl_out
+ * (zero it first) through a deterministic two-stage reduction using ws (>= c2_reduce_ws() floats). */
+size_t c2_reduce_ws(void);
+int c2_reparam_kl_fwd(const float* mu, const float* lv, const float* eps, int64_t B, int64_t L, int64_t ld,
+                      float inv_B, int use_own_kl, float* z32, void* zt, int zt_dtype, int64_t ldzt,
+                      float* kl_out, float* ws, void* stream);
+
+/* Backward:  dz = sum_s dZ[s] (+ extra_scale*extra);  dmu = dz + g_kl*dKL/dmu;
+ *   dlv = dz*eps*exp(lv)/(2 sqrt(v)) + g_kl*dKL/dlv.   g_kl = *g_kl_dev.  Outputs dtype out_dtype. */
+int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64_t slab_stride, const float* extra,
+                      int64_t ldextra, const float* extra_scale_dev, const float* mu, const float* lv,
+                      const float* eps, int64_t B, int64_t L, int64_t ld, float inv_B, int use_own_kl,
+                      const float* g_kl_dev, void* dmu, void* dlv, int out_dtype, int64_t ldout, void* stream);
+
+/* NB reconstruction loss, forward AND backward in one pass over [B,G]
+ * (celligner2.py:298-309, losses.py:27-65, _utils.py:8-24 incl. the one-hot quirk):
+ *   p = softmax(logits); mu = sizefactor*p; theta_b = exp(q_b . theta^T) with q_b the scatter-quirk
+ *   vector of the multi-hot row; ll as losses.py:57-65; recon = -(1/Bn) sum goodloc*ll.
+ * Adds recon to *loss_out; writes dlogits (dtype dl_dtype, unit upstream gradient) and dtheta [G,C].
+ * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set non-zero if a cond value is outside [0,C). */
+size_t c2_recon_nb_ws(int64_t B, int64_t G, int C);
+int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
+                        int64_t ldg, const float* sizefactor, const float* theta, const int64_t* cond, int C,
+                        int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
+                        int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, void* stream);
+
+/* MSE reconstruction (intent of celligner2.py:283-285; losses.py:9-24):  r = relu(logits);
+ *   recon = (1/Bn) sum goodloc*(r-x)^2;  dlogits = (2/Bn)*goodloc*(r-x)*[logits>0]. */
+int c2_recon_mse_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
+                         int64_t ldg, int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits,
+                         int dl_dtype, int64_t lddl, float* ws, void* stream);
+
+/* classifier_hb_loss (losses.py:318-333), forward and backward; MUTATES classes in place (-1 -> 0)
+ * exactly as the reference does.  du: unit-upstream gradient, dtype du_dtype. */
+int c2_classifier_loss_fwd_bwd(const float* u, int64_t ldu, int64_t* classes, int64_t B, int P, float betaclass,
+                               float* loss_out, void* du, int du_dtype, int64_t lddu, float* ws, void* stream);
+
+/* partition() of _utils.py:27-36 + the pair loops of losses.py:232-248, as per-row partition ids and a
+ * pair-weight table:  mmd = beta * sum_{a,b rows} Wt[part[a]][part[b]] * K(f_a, f_b).
+ * part_id [B] int32 (order of torch.unique(dim=0); main-dataset rows merged into partition 0);
+ * wt [C2_MMD_MAX_PARTS^2] fp32.  main_col = -1 for none; boundary = -1 for none.
+ * status_dev set non-zero where the reference would raise (too many/few partitions, empty main).
+ * ws: int64 workspace of c2_partition_ws(B) BYTES. */
+size_t c2_partition_ws(int64_t B);
+int c2_partition(const int64_t* cond, int64_t B, int C, int n_conditions, int main_col, int boundary,
+                 int32_t* part_id, float* wt, void* ws, int32_t* status_dev, void* stream);
+
+/* Multi-scale RBF MMD (losses.py:127-208) over rows [row0,row0+Bl) of feat against ALL Bg rows, forward and
+ * backward:   loss += beta * sum_{i local, j} wt*K;   dfeat[i] (local rows, fp32, [Bl,D]) for unit upstream.
+ * feat dtype f_dtype [Bg, ldf].  ws: c2_mmd_ws(Bl,Bg,D) floats. */
+size_t c2_mmd_ws(int64_t Bl, int64_t Bg, int64_t D);
+int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
+                   int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out, float* dfeat,
+                   int64_t lddf, float* ws, void* stream);
+
+/* torch.optim.Adam step as trainer.py:262-266,316-323 configures it (L2 weight decay added to the gradient,
+ * optional clip_grad_value_), over a table of tensors.  desc_host: array of n c2_adam_tensor (HOST memory,
+ * copied by value into the launch).  step_t >= 1.  shadow (bf16 copy of the updated weights, may be NULL)
+ * is refreshed in the same pass for bf16-operand GEMMs. */
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    void* shadow_bf16; /* NULL or [n] bf16 */
+    int64_t n;
+} c2_adam_tensor;
+int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float clip_value, int64_t step_t, void* stream);
+
+/* fp32 -> bf16 copy (initial weight shadows), n elements. */
+int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* Device-resident dataset -> batch (replaces AnnotatedDataset.__getitem__ + custom_collate + .to(device),
+ * dataset/celligner2/anndata.py:89-105, trainers/celligner2/_utils.py:188-225, trainer.py:274-275):
+ * rows idx[0..n) of x/goodloc/sizefactor/cond/classes are gathered into dense batch tensors; xin
+ * (= log(1+x) or x, dtype xin_dtype) is produced in the same pass (may be NULL). */
+int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
+                   const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n, float* x_out,
+                   uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
+                   int xin_dtype, int64_t ldxin, int apply_log, void* stream);
+
+/* y[i] = a*x[i] + y[i] (a = *a_dev), fp32; used to merge loss-branch gradients. */
+int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2MI_H */

@@ -1,0 +1,344 @@
+"""Per-entry-point parity: HIP kernels (through the C-ABI) vs the CPU oracle, same seeded inputs.
+Tolerances: fp32 1e-4 relative (north_star); bf16-operand GEMMs 1e-2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c2_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from celligner2_amd import ops
+    return ops
+
+
+def T(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel(a, b):
+    return gu.relerr(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 19000), (37, 300, 130), (4, 19000, 16), (512, 1000, 515)])
+def test_linear_three_layouts(dtype, tol, M, N, K):
+    ops = _ops()
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ta, tw, tdy = T(a, dtype), T(w, dtype), T(dy, dtype)
+    # the oracle sees the operands the kernel sees (bf16-rounded in bf16 mode)
+    a64, w64, dy64 = (t.float().cpu().numpy().astype(np.float64) for t in (ta, tw, tdy))
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(ta, tw, y, bias=T(bias))
+    assert rel(y, a64 @ w64.T + bias) < tol
+    for ns in (2, 3):
+        ys = torch.empty(ns, M, N, device=DEV)
+        ops.linear_fwd(ta, tw, ys, nslab=ns)
+        assert rel(ys.sum(0), a64 @ w64.T) < tol
+    alpha = T(np.array([0.5], np.float32))
+    da = torch.empty(M, K, device=DEV)
+    ops.linear_dgrad(tdy, tw, da, alpha=alpha)
+    assert rel(da, 0.5 * dy64 @ w64) < tol
+    das = torch.empty(2, M, K, device=DEV)
+    ops.linear_dgrad(tdy, tw, das, nslab=2)
+    assert rel(das.sum(0), dy64 @ w64) < tol
+    dw = torch.empty(N, K, device=DEV)
+    ops.linear_wgrad(tdy, ta, dw)
+    assert rel(dw, dy64.T @ a64) < tol
+    dws = torch.empty(3, N, K, device=DEV)
+    ops.linear_wgrad(tdy, ta, dws, nslab=3)
+    out = torch.empty(N, K, device=DEV)
+    ops.sum_slabs(dws, out)
+    assert rel(out, dy64.T @ a64) < tol
+
+
+def test_linear_unaligned_views():
+    """Operands with odd leading dimensions / offsets take the scalar-load path."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    M, N, K = 70, 50, 45
+    abig = T(rng.standard_normal((M, K + 3)).astype(np.float32))
+    wbig = T(rng.standard_normal((N, K + 1)).astype(np.float32))
+    a, w = abig[:, 1:K + 1], wbig[:, :K]
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(a, w, y)
+    assert rel(y, a.cpu().double().numpy() @ w.cpu().double().numpy().T) < 1e-5
+
+
+@pytest.mark.parametrize("H,C,p,use_ln", [(64, 3, 0.0, 1), (1024, 2, 0.1, 1), (1500, 0, 0.05, 1), (96, 4, 0.0, 0)])
+@pytest.mark.parametrize("act_dtype", [torch.float32, torch.bfloat16])
+def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
+    ops = _ops()
+    rng = np.random.default_rng(H + C)
+    B, ns = 37, 2
+    y = rng.standard_normal((ns, B, H)).astype(np.float32)
+    bias = rng.standard_normal(H).astype(np.float32)
+    cond = np.zeros((B, max(C, 1)), np.int64)
+    cond[np.arange(B), rng.integers(0, max(C, 1), B)] = 1
+    cond[0, :] = 1  # a multi-hot row
+    wc = rng.standard_normal((H, max(C, 1))).astype(np.float32)
+    mask = (rng.uniform(size=(B, H)) > p).astype(np.uint8) if p > 0 else None
+    dout = rng.standard_normal((2, B, H)).astype(np.float32)
+    extra = rng.standard_normal((B, H)).astype(np.float32)
+    # oracle: a = identity input so that h = Y; weights = identity is wasteful, use the block functions directly
+    h_in = y.sum(0).astype(np.float64)
+    out64, cache = orc._block_fwd(h_in, np.eye(H), bias.astype(np.float64), cond[:, :C].astype(np.float64) if C else None,
+                                  wc[:, :C].astype(np.float64) if C else None,
+                                  mask.astype(np.float64) if mask is not None else None, p, bool(use_ln))
+    act = torch.empty(B, H, device=DEV, dtype=act_dtype)
+    yhat = torch.empty(B, H, device=DEV)
+    rstd = torch.empty(B, device=DEV)
+    ops.epilogue_fwd(T(y), T(bias), T(cond[:, :C]) if C else None, T(wc[:, :C].copy()) if C else None,
+                     T(mask) if mask is not None else None, p, use_ln, act, yhat, rstd)
+    tol = 1e-4 if act_dtype == torch.float32 else 1e-2
+    assert rel(act, out64) < tol
+    assert rel(yhat, cache[2]) < 1e-4
+    # backward: dout = sum of 2 slabs + 0.25*extra
+    dtot = dout.sum(0).astype(np.float64) + 0.25 * extra
+    _, dW, db, dWc = orc._block_bwd(dtot, cache, np.eye(H), True, C > 0, need_da=False)
+    # dh = dW of an identity-weight block with a = h_in ... recover dh directly:
+    a_, cond_, yh, rs, mk, p_, ln_ = cache
+    d = dtot * (mk / (1 - p) if mk is not None else 1.0) * (yh > 0)
+    dh64 = (d - d.mean(1, keepdims=True) - yh * (d * yh).mean(1, keepdims=True)) * rs if use_ln else d
+    dh = torch.empty(B, H, device=DEV, dtype=act_dtype)
+    ops.epilogue_bwd(T(dout), T(mask) if mask is not None else None, p, use_ln, yhat, rstd, dh, extra=T(extra),
+                     extra_scale=T(np.array([0.25], np.float32)))
+    assert rel(dh, dh64) < (2e-4 if act_dtype == torch.float32 else 1e-2)
+    # bias / cond grads from the kernel's own dh
+    dh_np = dh.float().cpu().numpy().astype(np.float64)
+    ws = torch.empty(ops.bias_cond_grad_ws(B, H, C), device=DEV)
+    dbt = torch.empty(H, device=DEV)
+    dwct = torch.empty(H, C, device=DEV) if C else None
+    ops.bias_cond_grad(dh, T(cond[:, :C]) if C else None, dbt, dwct, ws)
+    assert rel(dbt, dh_np.sum(0)) < 1e-5
+    if C:
+        assert rel(dwct, dh_np.T @ cond[:, :C]) < 1e-5
+
+
+@pytest.mark.parametrize("use_own_kl", [0, 1])
+def test_reparam_kl(use_own_kl):
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    B, Ld = 130, 10
+    mu, lv, eps = (rng.standard_normal((B, Ld)).astype(np.float32) for _ in range(3))
+    z64 = orc.reparam(mu.astype(np.float64), lv.astype(np.float64), eps.astype(np.float64))
+    kl64, dmu_kl, dlv_kl = orc.kl_loss(mu.astype(np.float64), lv.astype(np.float64), bool(use_own_kl))
+    z32 = torch.empty(B, Ld, device=DEV)
+    zt = torch.empty(B, Ld, device=DEV, dtype=torch.bfloat16)
+    kl = torch.zeros(1, device=DEV)
+    ws = torch.empty(int(ops.lib.c2_reduce_ws()), device=DEV)
+    ops.reparam_kl_fwd(T(mu), T(lv), T(eps), 1.0 / B, use_own_kl, z32, zt, kl, ws)
+    assert rel(z32, z64) < 1e-5 and rel(zt, z64) < 1e-2
+    assert abs(kl.item() - kl64) < 1e-4 * abs(kl64)
+    dz = rng.standard_normal((2, B, Ld)).astype(np.float32)
+    gk = 0.3
+    dzt = dz.sum(0).astype(np.float64)
+    v = np.exp(lv.astype(np.float64)) + 1e-4
+    dmu64 = dzt + gk * dmu_kl
+    dlv64 = dzt * eps * np.exp(lv.astype(np.float64)) / (2 * np.sqrt(v)) + gk * dlv_kl
+    dmu = torch.empty(B, Ld, device=DEV)
+    dlv = torch.empty(B, Ld, device=DEV)
+    ops.reparam_kl_bwd(T(dz), T(mu), T(lv), T(eps), 1.0 / B, use_own_kl, T(np.array([gk], np.float32)), dmu, dlv)
+    assert rel(dmu, dmu64) < 1e-5 and rel(dlv, dlv64) < 1e-5
+
+
+def _nb_inputs(rng, B, G, C, multi=False, big_counts=False):
+    o = rng.standard_normal((B, G)).astype(np.float32) * 2
+    depth = rng.uniform(0.5, 2, (B, 1))
+    gene = np.exp(rng.normal(1.0 if not big_counts else 5.0, 1.5, (1, G)))
+    x = rng.poisson(depth * gene).astype(np.float32)
+    good = rng.uniform(size=(B, G)) > 0.01
+    cond = np.zeros((B, C), np.int64)
+    cond[np.arange(B), rng.integers(0, C, B)] = 1
+    if multi:
+        cond[0, :] = 1      # pattern "only ones" when C == 2
+        cond[1, :] = 0      # pattern "only zeros"
+    theta = rng.standard_normal((G, C)).astype(np.float32)
+    return o, x, good, x.sum(1).astype(np.float32), theta, cond
+
+
+@pytest.mark.parametrize("B,G,C,multi", [(5, 96, 2, True), (9, 1000, 3, False), (3, 3001, 2, False), (6, 5000, 2, True),
+                                         (4, 19000, 2, False), (3, 25000, 4, False)])
+@pytest.mark.parametrize("dl_dtype", [torch.float32, torch.bfloat16])
+def test_recon_nb(B, G, C, multi, dl_dtype):
+    ops = _ops()
+    rng = np.random.default_rng(G + B)
+    o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C, multi, big_counts=(G == 5000))
+    recon64, do64, dth64 = orc.nb_loss(o.astype(np.float64), x.astype(np.float64), good, sf.astype(np.float64),
+                                       theta.astype(np.float64), cond)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, G, device=DEV, dtype=dl_dtype)
+    dth = torch.empty(G, C, device=DEV)
+    ws = torch.empty(ops.recon_nb_ws(B, G, C), device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dth, ws, status)
+    assert status.item() == 0
+    assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
+    assert rel(dl, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
+    assert rel(dth, dth64) < 1e-4
+
+
+def test_recon_nb_golden_wide_row():
+    """The [4,19000] NB vector produced by the reference itself."""
+    ops = _ops()
+    z, _ = gu.load("nb_wide_row")
+    B, G = z["op/x"].shape
+    C = z["op/theta"].shape[1]
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, G, device=DEV)
+    dth = torch.empty(G, C, device=DEV)
+    ws = torch.empty(ops.recon_nb_ws(B, G, C), device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_nb(T(z["op/logits"]), T(z["op/x"]), T(z["op/goodloc"]), T(z["op/sizefactor"]), T(z["op/theta"]),
+                 T(z["op/batch"]), 1.0 / B, loss, dl, dth, ws, status)
+    assert abs(loss.item() - z["op/recon"][0]) < 1e-4 * abs(z["op/recon"][0])
+    assert rel(dl, z["op/dlogits"]) < 1e-4
+    assert rel(dth, z["op/dtheta"]) < 1e-4
+
+
+def test_recon_nb_flags_bad_condition_values():
+    ops = _ops()
+    rng = np.random.default_rng(0)
+    o, x, good, sf, theta, cond = _nb_inputs(rng, 4, 64, 2)
+    cond[2, 0] = -1
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 0.25, torch.zeros(1, device=DEV),
+                 torch.empty(4, 64, device=DEV), torch.empty(64, 2, device=DEV),
+                 torch.empty(ops.recon_nb_ws(4, 64, 2), device=DEV), status)
+    assert status.item() != 0
+
+
+def test_recon_mse():
+    ops = _ops()
+    rng = np.random.default_rng(1)
+    B, G = 17, 333
+    o = rng.standard_normal((B, G)).astype(np.float32)
+    x = np.abs(rng.standard_normal((B, G))).astype(np.float32)
+    good = rng.uniform(size=(B, G)) > 0.05
+    r64, d64 = orc.mse_loss(o.astype(np.float64), x.astype(np.float64), good)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, G, device=DEV)
+    ws = torch.empty(int(ops.lib.c2_reduce_ws()), device=DEV)
+    ops.recon_mse(T(o), T(x), T(good), 1.0 / B, loss, dl, ws)
+    assert abs(loss.item() - r64) < 1e-5 * abs(r64) and rel(dl, d64) < 1e-5
+
+
+@pytest.mark.parametrize("P", [1, 5, 30, 100])
+def test_classifier_loss(P):
+    ops = _ops()
+    rng = np.random.default_rng(P)
+    B = 77
+    u = (rng.standard_normal((B, P)) * 3).astype(np.float32)
+    y = np.zeros((B, P), np.int64)
+    y[np.arange(B), rng.integers(0, P, B)] = 1
+    y[rng.uniform(size=B) < 0.3] = -1
+    l64, du64 = orc.classifier_hb_loss(u.astype(np.float64), y, 0.8)
+    loss = torch.zeros(1, device=DEV)
+    du = torch.empty(B, P, device=DEV)
+    ty = T(y)
+    ws = torch.empty(int(ops.lib.c2_reduce_ws()), device=DEV)
+    ops.classifier_loss(T(u), ty, 0.8, loss, du, ws)
+    assert abs(loss.item() - l64) < 1e-4 * abs(l64) and rel(du, du64) < 1e-4
+    assert (ty.cpu().numpy() == np.where(y == -1, 0, y)).all(), "classes must be mutated in place like the reference"
+
+
+@pytest.mark.parametrize("B,D,C,main,boundary,multi", [(64, 10, 3, None, None, False), (200, 64, 5, 1, None, False),
+                                                       (96, 5, 4, None, 2, True), (150, 100, 2, None, None, False),
+                                                       (33, 16, 3, 0, None, True)])
+def test_partition_and_mmd(B, D, C, main, boundary, multi):
+    ops = _ops()
+    rng = np.random.default_rng(B + D)
+    f = rng.standard_normal((B, D)).astype(np.float32)
+    cond = np.zeros((B, C), np.int64)
+    lab = rng.integers(0, C, B)
+    lab[:C] = np.arange(C)
+    cond[np.arange(B), lab] = 1
+    if multi:
+        cond[np.arange(B), rng.integers(0, C, B)] = 1
+    try:
+        m64, d64 = orc.mmd_loss(f.astype(np.float64), cond, C, 7.0, boundary, main)
+    except (IndexError, RuntimeError):
+        pytest.skip("reference raises for this partition layout")
+    parts = orc.partition_index(cond, main)
+    part_id = torch.empty(B, device=DEV, dtype=torch.int32)
+    wt = torch.empty(64 * 64, device=DEV)
+    ws_p = torch.empty(int(ops.lib.c2_partition_ws(B)), device=DEV, dtype=torch.uint8)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.partition(T(cond), C, main, boundary, part_id, wt, ws_p, status)
+    assert status.item() == 0
+    pid = part_id.cpu().numpy()
+    for k, idx in enumerate(parts):
+        assert (pid[idx] == k).all()
+    loss = torch.zeros(1, device=DEV)
+    df = torch.empty(B, D, device=DEV)
+    ws = torch.empty(ops.mmd_ws(B, B, D), device=DEV)
+    ops.mmd(T(f), part_id, wt, 0, B, 7.0, loss, df, ws)
+    assert abs(loss.item() - m64) < 1e-4 * max(abs(m64), 1e-3), (loss.item(), m64)
+    assert rel(df, d64) < 2e-4
+    # row-sharded form (data-parallel): two shards reproduce the full gradient and loss
+    h = B // 2
+    loss2 = torch.zeros(1, device=DEV)
+    d0 = torch.empty(h, D, device=DEV)
+    d1 = torch.empty(B - h, D, device=DEV)
+    ops.mmd(T(f), part_id, wt, 0, h, 7.0, loss2, d0, torch.empty(ops.mmd_ws(h, B, D), device=DEV))
+    ops.mmd(T(f), part_id, wt, h, B - h, 7.0, loss2, d1, torch.empty(ops.mmd_ws(B - h, B, D), device=DEV))
+    assert abs(loss2.item() - m64) < 1e-4 * max(abs(m64), 1e-3)
+    assert rel(torch.cat([d0, d1]), d64) < 2e-4
+
+
+def test_adam_matches_oracle():
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    shapes = [(19, 7), (1000,), (33, 128), (5,)]
+    params = {f"p{i}": rng.standard_normal(s).astype(np.float32) for i, s in enumerate(shapes)}
+    tp = {k: T(v.copy()) for k, v in params.items()}
+    tm = {k: torch.zeros_like(v) for k, v in tp.items()}
+    tv = {k: torch.zeros_like(v) for k, v in tp.items()}
+    sh = {k: torch.empty_like(v, dtype=torch.bfloat16) for k, v in tp.items()}
+    state = {}
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    for step in range(1, 4):
+        grads = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in params.items()}
+        orc.adam_step(p64, {k: g.astype(np.float64) for k, g in grads.items()}, state, clip_value=1.5)
+        tg = {k: T(g) for k, g in grads.items()}
+        ops.adam_step([(tp[k], tg[k], tm[k], tv[k], sh[k]) for k in tp], 1e-3, 0.9, 0.999, 0.01, 0.04, 1.5, step)
+    for k in tp:
+        assert rel(tp[k], p64[k]) < 1e-6
+        assert rel(tm[k], state[k][0]) < 1e-5 and rel(tv[k], state[k][1]) < 1e-5
+        assert torch.equal(sh[k], tp[k].to(torch.bfloat16))
+
+
+def test_prep_and_gather():
+    ops = _ops()
+    rng = np.random.default_rng(2)
+    N, G, C, P = 50, 76, 3, 4
+    X = rng.poisson(3.0, (N, G)).astype(np.float32)
+    good = rng.uniform(size=(N, G)) > 0.1
+    sf = X.sum(1).astype(np.float32)
+    cond = rng.integers(0, 2, (N, C)).astype(np.int64)
+    cls = rng.integers(-1, 2, (N, P)).astype(np.int64)
+    idx = rng.integers(0, N, 21).astype(np.int64)
+    xo = torch.empty(21, G, device=DEV)
+    go = torch.empty(21, G, device=DEV, dtype=torch.bool)
+    so = torch.empty(21, device=DEV)
+    co = torch.empty(21, C, device=DEV, dtype=torch.int64)
+    po = torch.empty(21, P, device=DEV, dtype=torch.int64)
+    xin = torch.empty(21, G, device=DEV, dtype=torch.bfloat16)
+    ops.gather_rows(T(X), T(good), T(sf), T(cond), T(cls), T(idx), xo, go, so, co, po, xin, True)
+    assert np.array_equal(xo.cpu().numpy(), X[idx]) and np.array_equal(go.cpu().numpy(), good[idx])
+    assert np.array_equal(so.cpu().numpy(), sf[idx]) and np.array_equal(co.cpu().numpy(), cond[idx])
+    assert np.array_equal(po.cpu().numpy(), cls[idx])
+    assert rel(xin, np.log(1 + X[idx].astype(np.float64))) < 1e-2
+    out = torch.empty(N, G, device=DEV)
+    ops.prep_input(T(X), out, True)
+    assert rel(out, np.log(1 + X.astype(np.float64))) < 1e-6
