@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the Celligner2 training step (forward + backward + Adam) on MI355X.
+
+python bench.py --gpus N --steps K --warmup W      (N>1: launched under torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[3], SURVEY.md 8(d) "C4"): synthetic 100k x 19k expression matrix resident in
+HBM, hidden [1024,512], latent 64, 3 conditions, NB reconstruction, multi-dataset MMD on z, LayerNorm,
+dropout 0.05, Adam(lr 1e-3, eps 0.01, weight_decay 0.04); gene-width GEMMs with bf16 operands / fp32
+accumulate; weak scaling, 4096 cells per GPU per step.  A step = exactly Trainer.on_iteration of the reference
+(trainer.py:305-323) on a batch gathered from the device-resident dataset.
+
+Prints ONE JSON line (rank 0).  `roofline`: the gene-width MFMA GEMMs (the dominant kernel), timed with events on
+their own stream inside the timed region.  `cpu_baseline`: the numpy oracle (oracle/c2_oracle.py, a port) timed
+on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: G, hidden, latent, C, P, cls_hidden, per-GPU batch, N rows, beta
+    "c4": dict(G=19000, hidden=[1024, 512], latent=64, C=3, P=0, cls_hidden=[32], B=4096, N=100000, beta=1.0,
+               desc="synthetic 100k x 19k, hidden [1024,512], latent 64, NB + MMD, 3 conditions"),
+    "c2": dict(G=19000, hidden=[256, 128], latent=16, C=2, P=30, cls_hidden=[32, 64], B=128, N=11400, beta=500.0,
+               desc="CCLE+TCGA shape 11.4k x 19k, hidden [256,128], latent 16, NB + MMD + classifier"),
+}
+
+
+def synth_dataset(cfg, device, seed=2020):
+    """Synthetic NB-like counts generated on the device (there is no network / real matrix)."""
+    from celligner2_amd.dataset import DeviceDataset
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    N, G, C, P = cfg["N"], cfg["G"], cfg["C"], cfg["P"]
+    gene = torch.exp(torch.randn(1, G, device=device, generator=g) * 1.5 + 1.5)
+    X = torch.empty(N, G, device=device)
+    good = torch.empty(N, G, device=device, dtype=torch.bool)
+    for s in range(0, N, 8192):
+        e = min(N, s + 8192)
+        depth = torch.empty(e - s, 1, device=device).uniform_(0.5, 2.0, generator=g)
+        X[s:e] = torch.poisson(depth * gene, generator=g)
+        good[s:e] = torch.rand(e - s, G, device=device, generator=g) > 0.005
+    lab = torch.randint(0, C, (N,), device=device, generator=g)
+    cond = torch.zeros(N, C, dtype=torch.int64, device=device)
+    cond[torch.arange(N, device=device), lab] = 1
+    pred = None
+    if P > 0:
+        pl = torch.randint(0, P, (N,), device=device, generator=g)
+        pred = torch.zeros(N, P, dtype=torch.int64, device=device)
+        pred[torch.arange(N, device=device), pl] = 1
+        pred[torch.rand(N, device=device, generator=g) < 0.2] = -1
+    return DeviceDataset.from_tensors(X, X.sum(1), good, cond, pred, minweight=0.2)
+
+
+def cpu_baseline(cfg, seconds=20.0):
+    """The numpy oracle's full step (forward + backward + Adam) on a bounded sample of the workload."""
+    from oracle import c2_oracle as orc
+    Bc = 256
+    ocfg = orc.Cfg(input_dim=cfg["G"], hidden_layer_sizes=cfg["hidden"], latent_dim=cfg["latent"],
+                   n_conditions=cfg["C"], n_predictors=cfg["P"], classifier_hidden_layer_sizes=cfg["cls_hidden"],
+                   recon_loss="nb", use_mmd=True, beta=cfg["beta"])
+    rng = np.random.default_rng(0)
+    params = orc.init_params(ocfg, 0, np.float32)
+    x = rng.poisson(rng.uniform(0.5, 2, (Bc, 1)) * np.exp(rng.normal(1.5, 1.5, (1, cfg["G"])))).astype(np.float32)
+    cond = np.zeros((Bc, cfg["C"]), np.int64)
+    cond[np.arange(Bc), rng.integers(0, cfg["C"], Bc)] = 1
+    batch = dict(x=x, batch=cond, sizefactor=x.sum(1), goodloc=np.ones_like(x, dtype=bool))
+    if cfg["P"]:
+        cls = np.zeros((Bc, cfg["P"]), np.int64)
+        cls[np.arange(Bc), rng.integers(0, cfg["P"], Bc)] = 1
+        batch["classes"] = cls
+    state = {}
+    times = []
+    t_end = time.time() + seconds
+    n = 0
+    while n < 2 or (time.time() < t_end and n < 50):
+        eps = rng.standard_normal((Bc, cfg["latent"])).astype(np.float32)
+        t0 = time.time()
+        out = orc.forward_backward(params, ocfg, batch, eps, gscale=(1, 1e-3, 1, 1))
+        orc.adam_step(params, out["grads"], state)
+        times.append(time.time() - t0)
+        n += 1
+    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return dict(value=Bc / med, unit="cells/s", cores=cores, kind="port",
+                sample=f"{len(times)} steps of {Bc} cells, same model/genes (numpy fp32 oracle, BLAS threads={cores})")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=0, help="cells per GPU per step (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+        from celligner2_amd.parallel import DataParallelStep
+        comm = DataParallelStep()
+
+    from celligner2_amd import ops
+    from celligner2_amd.model import Celligner2
+    from celligner2_amd.trainer import Celligner2Trainer
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    B = cfg["B"]
+    torch.manual_seed(2020)
+    model = Celligner2(cfg["G"], cfg["hidden"], cfg["latent"], 0.05, False, "nb", conditions=[f"c{i}" for i in range(cfg["C"])],
+                       use_mmd=True, mmd_on="z", beta=cfg["beta"], predictors=[f"p{i}" for i in range(cfg["P"])],
+                       classifier_hidden_layer_sizes=cfg["cls_hidden"], precision=args.precision)
+    data = synth_dataset(cfg, device)
+    trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=B * world, use_leiden=False,
+                                alpha_kl=1e-3, monitor=False, use_early_stopping=False, rng="device", world=comm,
+                                seed=2020)
+    trainer.initialize_loaders()
+    model.train()
+    names = {id(p): n for n, p in model.named_parameters()}
+    from celligner2_amd.optim import FusedAdam
+    trainer.optimizer = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=0.01,
+                                  weight_decay=0.04, shadow_lookup=lambda p: model._engine().shadow_for_adam(names[id(p)]))
+    trainer.epoch, trainer.iter = 0, 0
+    from collections import defaultdict
+    trainer.iter_logs = defaultdict(list)
+
+    def batches():
+        while True:
+            for b in trainer.dataloader_train:
+                yield b
+
+    stream = batches()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.on_iteration(next(stream))
+    sync()
+    ops.PROFILE_GEMM = []  # (flops, start_event, end_event) of every gene-width GEMM launch in the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.on_iteration(next(stream))
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+    model._engine().check_status()
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    last = [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
+    assert all(np.isfinite(last)), f"non-finite losses {last}"
+
+    if rank == 0:
+        cells = B * world * args.steps
+        gemm_ms = sum(s.elapsed_time(e) for _, s, e in prof)
+        gemm_flops = sum(f for f, _, _ in prof)
+        n_launch = max(len(prof), 1)
+        peak = 2500.0 if args.precision == "bf16" else 157.3
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes",
+            "value": cells / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}; {B} cells/GPU/step, global batch {B * world}, "
+                                   f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "gemm_kernel (gene-width Linear fwd/dgrad/wgrad)",
+                         "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
+                         "gemm_ms_per_step": gemm_ms / args.steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,7 @@ if not os.path.exists(LIB_PATH):
     )
 lib = C.CDLL(LIB_PATH)
 
-i64, i32, f32, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+i64, i32, f32, f64, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
 
 class AdamTensor(C.Structure):
@@ -51,7 +51,7 @@ _SIGS = {
     "c2_partition": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "c2_mmd_ws": (sz, [i64, i64, i64]),
     "c2_mmd_fwd_bwd": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp, vp]),
-    "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, f32, i64, vp]),
+    "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f64, f64, f64, f64, f64, f64, i64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "c2_axpy": (i32, [vp, vp, vp, i64, vp]),

@@ -76,17 +76,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
 
 using namespace c2;
 
-extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, float clip_value, int64_t step_t, void* stream) {
+extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2,
+                            double eps, double weight_decay, double clip_value, int64_t step_t, void* stream) {
     C2_CHECK(desc_host || n_tensors == 0, "null descriptor table");
     C2_CHECK(step_t >= 1, "step_t must be >= 1");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step_t);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step_t);
+    const double bc1 = 1.0 - pow(beta1, (double)step_t);
+    const double bc2 = 1.0 - pow(beta2, (double)step_t);
     AdamHyper h;
-    h.step_size = (float)((double)lr / bc1);
-    h.beta1 = beta1; h.beta2 = beta2;
-    h.omb1 = (float)(1.0 - (double)beta1); h.omb2 = (float)(1.0 - (double)beta2);  // as torch: 1-beta in double
-    h.eps = eps; h.wd = weight_decay; h.clip = clip_value;
+    h.step_size = (float)(lr / bc1);
+    h.beta1 = (float)beta1; h.beta2 = (float)beta2;
+    h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);  // as torch: 1-beta in double
+    h.eps = (float)eps; h.wd = (float)weight_decay; h.clip = (float)clip_value;
     h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     for (int s = 0; s < n_tensors; s += kMaxT) {
         AdamTable tab;

@@ -1,0 +1,175 @@
+"""Input side of the training step: the tensors the reference's AnnotatedDataset + custom_collate build
+(celligner2/dataset/celligner2/anndata.py:8-166, dataset/celligner2/_utils.py:39-77,
+trainers/celligner2/_utils.py:79-185), kept RESIDENT on the GPU and gathered by row index with one kernel
+(c2_gather_rows) instead of per-sample __getitem__ + collate + host->device copies.
+
+Label encoding, NaN handling, size factors, the train/validation split and the stratifier weights are host
+logic (numpy/pandas on the AnnData-like object) restated from the cited lines; nothing here is on the GPU
+hot path except `gather`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def label_encoder_2D(adata, encoder, label_sets):
+    """dataset/celligner2/_utils.py:39-77: multi-hot matrix, -1 for labels missing from the encoder."""
+    labels = np.zeros((adata.shape[0], len(encoder.keys())))
+    miss = set()
+    for label_key in label_sets.keys():
+        unique_conditions = list(np.unique(adata.obs[label_key]))
+        if not set(unique_conditions).issubset(set(encoder.keys())):
+            miss = miss | set(unique_conditions) - set(encoder.keys())
+            print(f"Warning: Labels: {miss} in adata.obs[{label_key}] is not a subset of label-encoder!")
+            print("Therefore integer value of those labels is set to -1")
+    for k, values in label_sets.items():
+        for val in values:
+            sel = np.asarray(adata.obs[k] == val)
+            if val in miss:
+                for toset in set(values) - miss:
+                    labels[sel, encoder[toset]] = -1
+            else:
+                labels[sel, encoder[val]] = 1
+    return labels
+
+
+def train_test_split(adata, train_frac=0.85, cell_type_key=None):
+    """trainers/celligner2/_utils.py:79-116 (numpy GLOBAL rng, optionally per cell type)."""
+    if train_frac == 1:
+        return np.arange(adata.shape[0]), None
+    indices = np.arange(adata.shape[0])
+    if cell_type_key is not None:
+        train_idx, val_idx = [], []
+        for cell_type in adata.obs[cell_type_key].unique().tolist():
+            ct_idx = indices[np.asarray(adata.obs[cell_type_key] == cell_type)]
+            n_train = int(np.ceil(train_frac * len(ct_idx)))
+            np.random.shuffle(ct_idx)
+            train_idx.append(ct_idx[:n_train])
+            val_idx.append(ct_idx[n_train:])
+        return np.concatenate(train_idx), np.concatenate(val_idx)
+    n_train = int(np.ceil(train_frac * len(indices)))
+    np.random.shuffle(indices)
+    return indices[:n_train], indices[n_train:]
+
+
+class DeviceDataset:
+    """The reference's AnnotatedDataset with its tensors resident in HBM."""
+
+    def __init__(self, adata, goodloc=None, condition_keys=None, condition_encoder=None, cell_type_key=None,
+                 cell_type_encoder=None, predictor_encoder=None, predictor_keys=None, minweight=0.0, device="cuda"):
+        self.minweight = minweight
+        self.condition_keys = condition_keys
+        self.condition_encoder = condition_encoder
+        self.cell_type_key = cell_type_key
+        self.cell_type_encoder = cell_type_encoder
+        self.predictor_encoder = predictor_encoder
+        self.predictor_keys = predictor_keys
+        self.device = torch.device(device)
+        X = np.ascontiguousarray(np.asarray(adata.X), dtype=np.float32)
+        self.n, self.G = X.shape
+        sf = np.asarray(adata.obs["celligner2_size_factors"], dtype=np.float32).reshape(-1)
+        self.data = torch.from_numpy(X).to(self.device)
+        self.size_factors = torch.from_numpy(sf).to(self.device)
+        if goodloc is None:
+            goodloc = np.ones(X.shape, dtype=bool)
+        self.goodloc = torch.as_tensor(np.ascontiguousarray(goodloc), dtype=torch.bool).to(self.device)
+        self.conditions = None
+        self.predictors = None
+        if self.condition_keys is not None:
+            sets = {key: set(adata.obs[key]) for key in self.condition_keys}
+            self.conditions_np = label_encoder_2D(adata, self.condition_encoder, sets).astype(np.int64)
+            self.conditions = torch.from_numpy(self.conditions_np).to(self.device)
+        if self.predictor_keys is not None:
+            sets = {key: set(adata.obs[key]) for key in self.predictor_keys}
+            self.predictors_np = label_encoder_2D(adata, self.predictor_encoder, sets).astype(np.int64)
+            self.predictors = torch.from_numpy(self.predictors_np).to(self.device)
+
+    def __len__(self):
+        return self.n
+
+    @classmethod
+    def from_tensors(cls, data, size_factors, goodloc, conditions=None, predictors=None, minweight=0.0):
+        """Wrap tensors that already live on the GPU (synthetic benchmarks, pre-staged matrices)."""
+        self = cls.__new__(cls)
+        self.minweight = minweight
+        self.device = data.device
+        self.n, self.G = data.shape
+        self.data, self.size_factors, self.goodloc = data, size_factors, goodloc
+        self.conditions, self.predictors = conditions, predictors
+        self.condition_keys = ["condition"] if conditions is not None else None
+        self.predictor_keys = ["predictor"] if predictors is not None else None
+        if conditions is not None:
+            self.conditions_np = conditions.cpu().numpy()
+        if predictors is not None:
+            self.predictors_np = predictors.cpu().numpy()
+        return self
+
+    @property
+    def stratifier_weights(self):
+        """anndata.py:137-166 (note: -1 entries count as present, as in the reference)."""
+        strat = np.zeros(self.n).astype(float)
+        mats = [m.T for m in (getattr(self, "conditions_np", None), getattr(self, "predictors_np", None))
+                if m is not None]
+        for mat in mats:
+            w = []
+            for i in range(mat.shape[0]):
+                cnt = np.count_nonzero(mat[i])
+                w.append(0 if cnt == 0 else 1 / (cnt * mat.shape[0]))
+            for i in range(mat.shape[0]):
+                strat += np.where(mat[i], w[i], 0)
+        return strat + self.minweight
+
+    def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None):
+        """Batch dict for rows `idx` (int64 device tensor): the keys custom_collate would produce
+        (trainers/celligner2/_utils.py:188-225) plus `xin`, the encoder input written by the same kernel."""
+        n = idx.numel()
+        bufs = bufs if bufs is not None else {}
+
+        def get(key, shape, dtype):
+            t = bufs.get(key)
+            if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+                t = torch.empty(shape, dtype=dtype, device=self.device)
+                bufs[key] = t
+            return t
+
+        out = dict(x=get("x", (n, self.G), torch.float32), sizefactor=get("sizefactor", (n,), torch.float32),
+                   goodloc=get("goodloc", (n, self.G), torch.bool))
+        cond_o = cls_o = None
+        if self.condition_keys:
+            cond_o = out["batch"] = get("batch", (n, self.conditions.shape[1]), torch.int64)
+        if self.predictor_keys:
+            cls_o = out["classes"] = get("classes", (n, self.predictors.shape[1]), torch.int64)
+        xin = None
+        if xin_dtype is not None:
+            xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
+        ops.gather_rows(self.data, self.goodloc, self.size_factors, self.conditions if cond_o is not None else None,
+                        self.predictors if cls_o is not None else None, idx, out["x"], out["goodloc"],
+                        out["sizefactor"], cond_o, cls_o, xin, apply_log)
+        return out
+
+
+def make_dataset(adata, train_frac=0.9, condition_keys=None, cell_type_key=None, condition_encoder=None,
+                 cell_type_encoder=None, predictor_keys=None, predictor_encoder=None, min_weight=0.0, device="cuda"):
+    """trainers/celligner2/_utils.py:119-185."""
+    X = adata.X
+    goodloc = ~np.isnan(X)
+    if np.isnan(X).any():
+        nanme = np.nanmean(X, axis=0)
+        for i, val in enumerate(np.isnan(X).T):
+            X[val, i] = nanme[i]
+    size_factors = X.sum(1)
+    if len(size_factors.shape) < 2:
+        size_factors = np.expand_dims(size_factors, axis=1)
+    adata.obs["celligner2_size_factors"] = size_factors
+    train_idx, val_idx = train_test_split(adata, train_frac, cell_type_key)
+    kw = dict(condition_keys=condition_keys, cell_type_key=cell_type_key, condition_encoder=condition_encoder,
+              cell_type_encoder=cell_type_encoder, predictor_encoder=predictor_encoder, predictor_keys=predictor_keys,
+              minweight=min_weight, device=device)
+    train = DeviceDataset(adata[train_idx, :], goodloc[train_idx, :], **kw)
+    if train_frac == 1:
+        return train, None
+    valid = DeviceDataset(adata[val_idx, :], goodloc[val_idx, :], **kw)
+    return train, valid

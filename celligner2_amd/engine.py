@@ -44,6 +44,7 @@ class StepEngine:
         self._shadow = {}
         self._shadow_ver = {}
         self.grad = {}
+        self._touched = set()
         self.world_size, self.rank = 1, 0
         self.comm = None  # set by parallel.DataParallelStep
         nh = len(cfg["hidden"])
@@ -95,13 +96,56 @@ class StepEngine:
             self._ws[key] = t
         return t
 
+    def _readiness_order(self):
+        """Parameter names in the order the backward pass finishes their gradients."""
+        order = [self.head + ".weight", self.head + ".bias", "theta"]
+        for blk in reversed(self.dec):
+            order += [blk.w, blk.wc]
+        order += ["classifier.classifier.0.weight", "classifier.classifier.0.bias"]
+        for blk in reversed(self.cls):
+            order += [blk.w]
+        order += ["encoder.mean_encoder.weight", "encoder.mean_encoder.bias", "encoder.log_var_encoder.weight",
+                  "encoder.log_var_encoder.bias"]
+        for blk in reversed(self.enc):
+            order += [blk.w, blk.b, blk.wc]
+        seen, out = set(), []
+        for n in order:
+            if n and n in self.p and n not in seen:
+                seen.add(n)
+                out.append(n)
+        out += [n for n in self.p if n not in seen]
+        return out
+
+    def _build_arena(self):
+        """One flat fp32 gradient arena (views per parameter) cut into three all-reduce buckets:
+        [decoder output layer + theta] [everything between] [encoder L0]."""
+        key = tuple((n, tuple(p.shape), p.requires_grad) for n, p in self.p.items())
+        if getattr(self, "_arena_key", None) == key:
+            return
+        self._arena_key = key
+        names = [n for n in self._readiness_order() if self.p[n].requires_grad]
+        offs, total = {}, 0
+        for n in names:
+            offs[n] = total
+            total += (self.p[n].numel() + 63) // 64 * 64
+        self.grad_flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
+        self.grad = {n: self.grad_flat[offs[n]:offs[n] + self.p[n].numel()].view(self.p[n].shape) for n in names}
+        first = {self.head + ".weight", self.head + ".bias", "theta"}
+        last = {self.enc[0].w, self.enc[0].b, self.enc[0].wc}
+        b0 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in first)
+        b2 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in last)
+        self.buckets = [(0, b0), (b0, total - b2), (total - b2, total)]
+
     def gbuf(self, name):
-        g = self.grad.get(name)
-        p = self.p[name]
-        if g is None or g.shape != p.shape:
-            g = torch.zeros_like(p, dtype=F32)
-            self.grad[name] = g
-        return g
+        self._build_arena()
+        self._touched.add(name)
+        return self.grad[name]
+
+    def _reduce_bucket(self, i):
+        if self.comm is not None and self.world_size > 1:
+            lo, hi = self.buckets[i]
+            if hi > lo:
+                self.comm.allreduce_bucket_async(self.grad_flat[lo:hi])
 
     def weight(self, name):
         """GEMM operand view of a weight: the fp32 parameter itself, or its bf16 shadow."""
@@ -287,6 +331,8 @@ class StepEngine:
             ws = self.buf("mmd.ws", (ops.mmd_ws(B, Bg, D),))
             ops.mmd(feat_all, part, wt, row0, B, cfg["beta"], losses[2:3], dfeat, ws)
             self._dfeat = dfeat
+        if self.comm is not None and self.world_size > 1:
+            self.comm.allreduce_scalars(losses)  # every term is already normalised by the GLOBAL batch
         return losses
 
     # ------------------------------------------------------------------ backward
@@ -295,6 +341,7 @@ class StepEngine:
         Fills self.grad[name] for every parameter with requires_grad and returns that dict."""
         cfg = self.cfg
         B, cond, masks = self._B, self._cond, self._masks
+        self._touched = set()  # parameters outside this step's graph get no gradient (torch leaves .grad None)
         gr, gk, gm, gc = g[0:1], g[1:2], g[2:3], g[3:4]
         rq = lambda n: self.p[n].requires_grad  # noqa: E731
         dlogits = self._ws["dlogits"]
@@ -316,6 +363,8 @@ class StepEngine:
             gt = self.gbuf("theta")
             gt.zero_()
             ops.axpy(self._ws["dtheta.unit"], gr, gt)
+        self._build_arena()
+        self._reduce_bucket(0)  # overlaps everything below
         # ---- decoder hidden blocks, then the first block (mmd_on='y' enters at its output)
         L = cfg["latent"]
         n_cls_slab = 1 if (self._has_cls and cfg["n_predictors"] > 0) else 0
@@ -360,8 +409,15 @@ class StepEngine:
         for i in range(len(self.enc) - 1, -1, -1):
             if i < need:
                 break
+            if i == 0:
+                self._reduce_bucket(1)  # overlaps the gene-width wgrad of encoder L0
             da = self._block_bwd(self.enc[i], da, self._enc_in[i], cond, masks, need_da=(i > need))
-        return {n: gbuf for n, gbuf in self.grad.items() if self.p[n].requires_grad}
+        if need > 0:
+            self._reduce_bucket(1)
+        self._reduce_bucket(2)
+        if self.comm is not None:
+            self.comm.wait_all()
+        return {n: self.grad[n] for n in self._touched}
 
     def _first_trainable_enc(self):
         for i, blk in enumerate(self.enc):

@@ -9,6 +9,31 @@ from . import _lib as L
 from ._lib import check, dt_code, lib, ptr, stream
 
 
+PROFILE_GEMM = None  # bench.py: list collecting (flops, start_event, end_event) of gene-width GEMM launches
+
+
+class _GemmTimer:
+    """Event pair on the launch stream around one gene-width GEMM (only while bench.py asks for it)."""
+
+    def __init__(self, M, N, K):
+        self.on = PROFILE_GEMM is not None and max(M, N, K) >= 2048 and min(M, N, K) >= 64
+        if self.on:
+            self.flops = 2.0 * M * N * K
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record()
+            PROFILE_GEMM.append((self.flops, self.s, self.e))
+        return False
+
+
 def _row_major(t, name):
     if t.dim() != 2 or t.stride(1) != 1:
         raise L.C2Error(f"{name}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
@@ -40,8 +65,9 @@ def linear_fwd(a, w, y, bias=None, nslab=1):
     assert tuple(y2.shape) == (M, N)
     ss = y.stride(0) if y.dim() == 3 else 0
     assert (y.dim() == 3 and y.shape[0] == nslab) or nslab == 1
-    check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), dt_code(a.dtype), M, N, K, ptr(y),
-                            _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), dt_code(a.dtype), M, N, K,
+                                ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
     return y
 
 
@@ -55,8 +81,9 @@ def linear_dgrad(dy, w, da, nslab=1, alpha=None):
     assert tuple(d2.shape) == (M, K)
     ss = da.stride(0) if da.dim() == 3 else 0
     assert (da.dim() == 3 and da.shape[0] == nslab) or nslab == 1
-    check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), dt_code(dy.dtype), M, N, K,
-                              ptr(da), _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), dt_code(dy.dtype), M, N,
+                                  K, ptr(da), _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
     return da
 
 
@@ -70,8 +97,9 @@ def linear_wgrad(dy, a, dw, nslab=1, alpha=None):
     assert tuple(d2.shape) == (N, K)
     ss = dw.stride(0) if dw.dim() == 3 else 0
     assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
-    check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), dt_code(dy.dtype), M, N, K,
-                              ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), dt_code(dy.dtype), M, N,
+                                  K, ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
     return dw
 
 

@@ -149,7 +149,8 @@ int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* pa
 /* torch.optim.Adam step as trainer.py:262-266,316-323 configures it (L2 weight decay added to the gradient,
  * optional clip_grad_value_), over a table of tensors.  desc_host: array of n c2_adam_tensor (HOST memory,
  * copied by value into the launch).  step_t >= 1.  shadow (bf16 copy of the updated weights, may be NULL)
- * is refreshed in the same pass for bf16-operand GEMMs. */
+ * is refreshed in the same pass for bf16-operand GEMMs.  Hyper-parameters are doubles so that 1-beta and the bias
+ * corrections are formed exactly as torch forms them (in double, then rounded to fp32). */
 typedef struct {
     float* p;
     const float* g;
@@ -158,8 +159,8 @@ typedef struct {
     void* shadow_bf16; /* NULL or [n] bf16 */
     int64_t n;
 } c2_adam_tensor;
-int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, float clip_value, int64_t step_t, void* stream);
+int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, double clip_value, int64_t step_t, void* stream);
 
 /* fp32 -> bf16 copy (initial weight shadows), n elements. */
 int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);

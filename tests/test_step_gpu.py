@@ -34,10 +34,23 @@ def build_model(meta, z, precision):
 
 
 @pytest.mark.parametrize("name", gu.step_cases())
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-2)])
+# fp32: the north_star bar, 1e-4 (max-norm relative).  bf16 on these TOY widths (G ~ 100, hidden 16-48, B 24-64) is
+# a plumbing check only: a bf16 rounding is averaged over so few terms that per-tensor L2 errors of a few percent are
+# expected; the 1e-2 bar of bf16 mode is enforced at a realistic width in test_bf16_step_midsize_vs_oracle below.
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-1)])
 def test_training_step_matches_reference(name, precision, tol):
     from celligner2_amd.optim import FusedAdam
+    from celligner2_amd.engine import StepEngine
     z, meta = gu.load(name)
+    StepEngine.WIDE = 64 if precision == "bf16" else 2048  # toy widths: make the widest layers take bf16 operands
+    try:
+        _run_case(z, meta, precision, tol)
+    finally:
+        StepEngine.WIDE = 2048
+
+
+def _run_case(z, meta, precision, tol):
+    from celligner2_amd.optim import FusedAdam
     model = build_model(meta, z, precision)
     eng = model._engine()
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=meta["adam"]["lr"], eps=meta["adam"]["eps"],
@@ -56,14 +69,18 @@ def test_training_step_matches_reference(name, precision, tol):
         eng.check_status()
         ref = z[f"s{s}/losses"]
         got = [recon.item(), kl.item(), mmd.item(), ce.item()]
-        ltol = tol if precision == "fp32" else 2e-2
+        ltol = min(tol, 1e-2)
         for i in range(4):
             assert abs(got[i] - ref[i]) <= ltol * max(abs(ref[i]), 1.0), (i, got, ref)
         for k, g in gu.group(z, f"s{s}/grad/").items():
             p = dict(model.named_parameters())[k]
             assert p.grad is not None, k
-            err = gu.relerr(p.grad.cpu().numpy(), g)
-            assert err < (tol if precision == "fp32" else 3e-2), (k, err)
+            if precision == "fp32":
+                err = gu.relerr(p.grad.cpu().numpy(), g)  # max-norm relative
+            else:  # bf16 operands: relative L2 error of the gradient tensor
+                gg = p.grad.double().cpu().numpy()
+                err = np.linalg.norm(gg - g) / max(np.linalg.norm(g), 1e-30)
+            assert err < tol, (k, err)
         if "classes" in batch:
             assert np.array_equal(batch["classes"].cpu().numpy(), z[f"s{s}/classes_after"])
         opt.step()
@@ -110,3 +127,41 @@ def test_eval_forward_no_grad_and_get_latent():
     e = np.exp(o["logits"] - o["logits"].max(1, keepdims=True))
     assert gu.relerr(rec.cpu().numpy(), e / e.sum(1, keepdims=True)) < 1e-4
     assert gu.relerr(y1.cpu().numpy(), o["y1"]) < 1e-4
+
+
+def test_bf16_step_midsize_vs_oracle():
+    """bf16-MFMA mode at a realistic width (G=4096, hidden [512,256], B=512): losses and every gradient tensor
+    within 1e-2 (relative L2) of the fp64 oracle -- the north_star tolerance for bf16 mode."""
+    from celligner2_amd.model import Celligner2
+    from oracle import c2_oracle as orc
+    G, hidden, L, C, P, B = 4096, [512, 256], 16, 3, 10, 512
+    rng = np.random.default_rng(0)
+    cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=hidden, latent_dim=L, n_conditions=C, n_predictors=P,
+                  recon_loss="nb", use_mmd=True, beta=100.0)
+    params = orc.init_params(cfg, 0, np.float32)
+    x = rng.poisson(rng.uniform(0.5, 2.0, (B, 1)) * np.exp(rng.normal(1.0, 1.5, (1, G)))).astype(np.float32)
+    cond = np.zeros((B, C), np.int64)
+    cond[np.arange(B), rng.integers(0, C, B)] = 1
+    cls = np.zeros((B, P), np.int64)
+    cls[np.arange(B), rng.integers(0, P, B)] = 1
+    cls[rng.uniform(size=B) < 0.2] = -1
+    batch = dict(x=x, batch=cond, sizefactor=x.sum(1).astype(np.float32), goodloc=rng.uniform(size=(B, G)) > 0.005,
+                 classes=cls)
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    ref = orc.forward_backward({k: v.astype(np.float64) for k, v in params.items()}, cfg, batch, eps.astype(np.float64),
+                               gscale=(1, 1e-3, 1, 1))
+    m = Celligner2(G, hidden, L, 0.0, False, "nb", conditions=[f"c{i}" for i in range(C)], use_mmd=True, beta=100.0,
+                   predictors=[f"p{i}" for i in range(P)], precision="bf16")
+    m.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    m.to(DEV).train()
+    m._forced_noise = dict(eps=torch.tensor(eps).to(DEV), masks={})
+    r, k, mm, ce = m(**{k_: torch.tensor(v).to(DEV) for k_, v in batch.items()})
+    (r + 1e-3 * k + mm + ce).backward()
+    assert m._engine().enc[0].gt == torch.bfloat16 and m._engine().head_t == torch.bfloat16
+    got = [r.item(), k.item(), mm.item(), ce.item()]
+    for i in range(4):
+        assert abs(got[i] - ref["losses"][i]) <= 1e-2 * max(abs(ref["losses"][i]), 1.0)
+    for n, p in m.named_parameters():
+        g, gr = p.grad.double().cpu().numpy(), ref["grads"][n]
+        err = np.linalg.norm(g - gr) / max(np.linalg.norm(gr), 1e-30)
+        assert err < 1e-2, (n, err)
