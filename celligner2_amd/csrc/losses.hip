@@ -1,10 +1,10 @@
 // Reconstruction (NB / MSE) and classifier losses: forward and analytic backward fused in one pass.
 //
-// NB kernel layout: one workgroup walks whole rows (cells); thread t owns the same gene columns in every row it
-// visits, so (a) the row's softmax statistics are two block reductions over register-held logits, (b) the
-// per-gene dispersion gradient is accumulated in registers across the workgroup's rows and leaves the kernel
-// as one partial row per workgroup (summed by a second tiny kernel: deterministic, no atomics).  HBM traffic
-// per cell = logits 4G + x 4G + goodloc 1G read, dlogits (2|4)G written: the algorithmic minimum.
+// NB kernel layout: one workgroup walks whole rows (cells) in four passes, re-reading the row from L1/L2 so that
+// HBM sees each byte once; thread t owns the same gene columns in every row, so the per-gene dispersion gradient
+// accumulates in an LDS array across the workgroup's rows and leaves the kernel as one partial row per workgroup
+// (summed by a second tiny kernel: deterministic, no atomics).  HBM traffic per cell = logits 4G + x 4G +
+// goodloc 1G read, dlogits (2|4)G written: the algorithmic minimum.
 #include "common.h"
 
 namespace c2 {
@@ -89,39 +89,111 @@ struct NbArgs {
     float inv_B;
 };
 
-template <typename TD, int NT, int NV, bool VEC>
+// fast transcendental forms: every argument here is a normal positive float (>= 1e-8)
+__device__ __forceinline__ float flog(float v) { return __logf(v); }
+__device__ __forceinline__ float frcp(float v) { return __frcp_rn(v); }
+
+__device__ __forceinline__ float lgamma_fast(float z) {
+    const bool small = z < 8.0f;
+    float prod = 1.0f, zs = z;
+    if (small) {
+        prod = z * (z + 1.f) * (z + 2.f) * (z + 3.f);
+        prod *= (z + 4.f) * (z + 5.f) * (z + 6.f) * (z + 7.f);
+        zs = z + 8.0f;
+    }
+    const float r = frcp(zs);
+    const float r2 = r * r;
+    const float series = r * (0.083333333333f + r2 * (-0.002777777778f + r2 * (0.000793650794f - r2 * 0.000595238095f)));
+    return (zs - 0.5f) * flog(zs) - zs + 0.918938533205f + series - flog(prod);
+}
+__device__ __forceinline__ float digamma_fast(float z) {
+    float corr = 0.f, zs = z;
+    if (z < 6.0f) {
+        float P = z, dP = 1.f;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            const float t = z + (float)k;
+            dP = dP * t + P;
+            P = P * t;
+        }
+        corr = dP * frcp(P);
+        zs = z + 6.0f;
+    }
+    const float r = frcp(zs);
+    const float r2 = r * r;
+    const float series = r2 * (0.083333333333f - r2 * (0.008333333333f - r2 * (0.003968253968f - r2 * 0.004166666667f)));
+    return flog(zs) - 0.5f * r - series - corr;
+}
+
+// One workgroup walks whole rows.  Nothing of a row is kept in registers between its passes: the row (76 KB at
+// 19k genes) is re-read from L1/L2, so HBM sees each byte once; the per-gene dispersion-gradient accumulator of the
+// workgroup lives in LDS (G floats), owned column-wise by the threads.
+//   pass 1  row max of the logits                       (HBM read of logits)
+//   pass 2  sum exp(logit - max)                        (L2)
+//   pass 3  S = sum_g p_g * gp_g                        (HBM read of x, goodloc; table from L2)
+//   pass 4  log-likelihood, dlogits = p*gp - p*S (written once), d(theta) accumulated in LDS
+template <typename TD, int NT, bool VEC>
 __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dacc[];  // [G rounded up to 4]
     __shared__ float red[32];
-    constexpr int NE = NV * 4;
     const int tid = threadIdx.x;
     const int64_t G = a.G;
-    // column of element e of this thread
-    auto col_of = [&](int e) -> int64_t {
-        if (VEC) return 4ll * (tid + NT * (e >> 2)) + (e & 3);
-        return (int64_t)tid + (int64_t)NT * e;
-    };
-    float dacc[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) dacc[e] = 0.f;
-    int cur_pat = -1;
-    int flushed = 0;
-    float loss_acc = 0.f;
+    const int64_t G4 = (G + 3) & ~int64_t(3);
     const float eps = 1e-8f;
+    for (int64_t c = tid; c < G4; c += NT) dacc[c] = 0.f;
+    int cur_pat = -1, flushed = 0;
+    float loss_acc = 0.f;
 
     auto flush = [&](int pat) {
+        __syncthreads();
         float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
         const bool first = !((flushed >> pat) & 1);
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int64_t c = col_of(e);
-            if (c < G) dst[c] = first ? dacc[e] : dst[c] + dacc[e];
-            dacc[e] = 0.f;
+        for (int64_t c = tid; c < G; c += NT) {
+            dst[c] = first ? dacc[c] : dst[c] + dacc[c];
+            dacc[c] = 0.f;
         }
         flushed |= 1 << pat;
+        __syncthreads();
+    };
+    // element visitor: f(column, logit, x, good, theta, k1, k2) for the columns of this thread
+    auto for_cols = [&](const float* orow, const float* xrow, const uint8_t* grow, const float* tth, const float* tk1,
+                        const float* tk2, bool need_x, auto&& f) {
+        if (VEC) {
+            for (int64_t c = 4ll * tid; c < G; c += 4ll * NT) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(orow + c);
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f}, t0 = xv, t1 = xv, t2 = xv;
+                unsigned mb = 0;
+                if (need_x) {
+                    xv = *reinterpret_cast<const f32x4*>(xrow + c);
+                    t0 = *reinterpret_cast<const f32x4*>(tth + c);
+                    t1 = *reinterpret_cast<const f32x4*>(tk1 + c);
+                    t2 = *reinterpret_cast<const f32x4*>(tk2 + c);
+                    mb = *reinterpret_cast<const unsigned*>(grow + c);
+                }
+                f(c, ov, xv, mb, t0, t1, t2);
+            }
+        } else {
+            for (int64_t c0 = 4ll * tid; c0 < G; c0 += 4ll * NT) {
+                f32x4 ov = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f}, t0 = {1.f, 1.f, 1.f, 1.f}, t1 = xv, t2 = xv;
+                unsigned mb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t c = c0 + k;
+                    if (c < G) {
+                        ov[k] = orow[c];
+                        if (need_x) {
+                            xv[k] = xrow[c]; t0[k] = tth[c]; t1[k] = tk1[c]; t2[k] = tk2[c];
+                            mb |= grow[c] ? (1u << (8 * k)) : 0u;
+                        }
+                    }
+                }
+                f(c0, ov, xv, mb, t0, t1, t2);
+            }
+        }
     };
 
     for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
-        // ---- pattern of the row (uniform over the block)
         int has0 = 0, has1 = 0, bad = 0;
         for (int j = 0; j < a.C; ++j) {
             const int64_t v = a.cond[row * a.C + j];
@@ -142,130 +214,86 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
         const float* xrow = a.x + row * a.ldx;
         const uint8_t* grow = a.goodloc + row * a.ldg;
         const float sf = a.sizefactor[row];
-        // ---- pass A: logits -> registers, row max, exp, row sum
-        float ev[NE];
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float scale = -a.inv_B;
+        // pass 1
         float mx = -INFINITY;
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int64_t c = 4ll * (tid + NT * i);
-                f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                if (c < G) v = *reinterpret_cast<const f32x4*>(orow + c);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ev[i * 4 + k] = v[k];
-                    mx = fmaxf(mx, v[k]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int64_t c = col_of(e);
-                ev[e] = c < G ? orow[c] : -INFINITY;
-                mx = fmaxf(mx, ev[e]);
-            }
-        }
+        for_cols(orow, xrow, grow, tth, tk1, tk2, false,
+                 [&](int64_t, f32x4 ov, f32x4, unsigned, f32x4, f32x4, f32x4) {
+                     mx = fmaxf(fmaxf(mx, fmaxf(ov[0], ov[1])), fmaxf(ov[2], ov[3]));
+                 });
         mx = block_max<NT>(mx, red);
+        // pass 2
         float sm = 0.f;
+        for_cols(orow, xrow, grow, tth, tk1, tk2, false,
+                 [&](int64_t, f32x4 ov, f32x4, unsigned, f32x4, f32x4, f32x4) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            ev[e] = __expf(ev[e] - mx);  // exp(-inf) = 0 for padding
-            sm += ev[e];
-        }
+                     for (int k = 0; k < 4; ++k) sm += __expf(ov[k] - mx);
+                 });
         sm = block_sum<NT>(sm, red);
         const float inv_sum = 1.0f / sm;
-        // ---- pass B: log-likelihood, gradient pieces
-        float pg[NE];  // p * gp
+        // pass 3
         float S = 0.f;
-        const float* tb_th = a.tab + (int64_t)(pat * 3 + 0) * G;
-        const float* tb_k1 = a.tab + (int64_t)(pat * 3 + 1) * G;
-        const float* tb_k2 = a.tab + (int64_t)(pat * 3 + 2) * G;
-        const float scale = -a.inv_B;
+        for_cols(orow, xrow, grow, tth, tk1, tk2, true,
+                 [&](int64_t, f32x4 ov, f32x4 xv, unsigned mb, f32x4 t0, f32x4, f32x4) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float xv[4], thv[4], k1v[4], k2v[4];
-            unsigned mbits = 0;
-            const int64_t c0 = VEC ? 4ll * (tid + NT * i) : 0;
-            if (VEC) {
-                f32x4 xx = {0.f, 0.f, 0.f, 0.f}, t0 = {1.f, 1.f, 1.f, 1.f}, t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
-                if (c0 < G) {
-                    xx = *reinterpret_cast<const f32x4*>(xrow + c0);
-                    t0 = *reinterpret_cast<const f32x4*>(tb_th + c0);
-                    t1 = *reinterpret_cast<const f32x4*>(tb_k1 + c0);
-                    t2 = *reinterpret_cast<const f32x4*>(tb_k2 + c0);
-                    mbits = *reinterpret_cast<const unsigned*>(grow + c0);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    xv[k] = xx[k]; thv[k] = t0[k]; k1v[k] = t1[k]; k2v[k] = t2[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int64_t c = col_of(i * 4 + k);
-                    const bool in = c < G;
-                    xv[k] = in ? xrow[c] : 0.f;
-                    thv[k] = in ? tb_th[c] : 1.f;
-                    k1v[k] = in ? tb_k1[c] : 0.f;
-                    k2v[k] = in ? tb_k2[c] : 0.f;
-                    mbits |= (in && grow[c]) ? (1u << (8 * k)) : 0u;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = i * 4 + k;
-                const bool m = (mbits >> (8 * k)) & 0xffu;
-                const float p = ev[e] * inv_sum;
-                const float mu = sf * p;
-                const float th = thv[k], x = xv[k];
-                const float tm = th + mu + eps;
-                const float ltm = logf(tm);
-                const float lme = logf(mu + eps);
-                const float zt = x + th;
-                // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
-                const float ll = k1v[k] - zt * ltm + x * lme + lgamma_pos(zt) - lgamma_pos(x + 1.0f);
-                const float rtm = 1.0f / tm;
-                // p*gp = -(m/B) * mu * dll/dmu,  dll/dmu = x/(mu+eps) - (theta+x)/(theta+mu+eps)
-                const float dmu_mu = x * mu / (mu + eps) - zt * mu * rtm;
-                // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
-                const float dth = k2v[k] - ltm - zt * rtm + digamma_pos(zt);
-                const float a_pg = m ? scale * dmu_mu : 0.f;
-                pg[e] = a_pg;
-                S += a_pg;
-                ev[e] = p;
-                loss_acc += m ? ll : 0.f;
-                dacc[e] += m ? scale * th * dth : 0.f;
-            }
-        }
+                     for (int k = 0; k < 4; ++k) {
+                         const float mu = sf * __expf(ov[k] - mx) * inv_sum;
+                         const float zt = xv[k] + t0[k];
+                         const float v = xv[k] * mu * frcp(mu + eps) - zt * mu * frcp(t0[k] + mu + eps);
+                         S += ((mb >> (8 * k)) & 0xffu) ? scale * v : 0.f;
+                     }
+                 });
         S = block_sum<NT>(S, red);
-        // ---- pass C: dlogits = p*gp - p*S
+        // pass 4
         TD* drow = reinterpret_cast<TD*>(a.dlogits) + row * a.lddl;
-        if (VEC) {
+        for_cols(orow, xrow, grow, tth, tk1, tk2, true,
+                 [&](int64_t c0, f32x4 ov, f32x4 xv, unsigned mb, f32x4 t0, f32x4 t1, f32x4 t2) {
+                     float d[4], dt[4];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int64_t c = 4ll * (tid + NT * i);
-                if (c < G) {
-                    float d[4];
+                     for (int k = 0; k < 4; ++k) {
+                         const bool m = (mb >> (8 * k)) & 0xffu;
+                         const float p = __expf(ov[k] - mx) * inv_sum;
+                         const float mu = sf * p;
+                         const float th = t0[k], x = xv[k];
+                         const float tm = th + mu + eps;
+                         const float ltm = flog(tm);
+                         const float zt = x + th;
+                         // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
+                         const float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lgamma_fast(zt) - lgamma_fast(x + 1.0f);
+                         const float rtm = frcp(tm);
+                         const float dmu_mu = x * mu * frcp(mu + eps) - zt * mu * rtm;  // mu * dll/dmu
+                         // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
+                         const float dth = t2[k] - ltm - zt * rtm + digamma_fast(zt);
+                         const float pg = m ? scale * dmu_mu : 0.f;
+                         d[k] = pg - p * S;
+                         dt[k] = m ? scale * th * dth : 0.f;
+                         loss_acc += m ? ll : 0.f;
+                     }
+                     if (VEC) {
+                         f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c0);
+                         acc[0] += dt[0]; acc[1] += dt[1]; acc[2] += dt[2]; acc[3] += dt[3];
+                         *reinterpret_cast<f32x4*>(dacc + c0) = acc;
+                         if (sizeof(TD) == 4) {
+                             f32x4 o = {d[0], d[1], d[2], d[3]};
+                             *reinterpret_cast<f32x4*>(drow + c0) = o;
+                         } else {
+                             u32x2 pk;
+                             pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
+                             pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
+                             *reinterpret_cast<u32x2*>(drow + c0) = pk;
+                         }
+                     } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] = pg[i * 4 + k] - ev[i * 4 + k] * S;
-                    if (sizeof(TD) == 4) {
-                        f32x4 o = {d[0], d[1], d[2], d[3]};
-                        *reinterpret_cast<f32x4*>(drow + c) = o;
-                    } else {
-                        u32x2 pk;
-                        pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
-                        pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
-                        *reinterpret_cast<u32x2*>(drow + c) = pk;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int64_t c = col_of(e);
-                if (c < G) st_from_f32<TD>(drow + c, pg[e] - ev[e] * S);
-            }
-        }
+                         for (int k = 0; k < 4; ++k)
+                             if (c0 + k < G) {
+                                 dacc[c0 + k] += dt[k];
+                                 st_from_f32<TD>(drow + c0 + k, d[k]);
+                             }
+                     }
+                 });
     }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
@@ -276,14 +304,15 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
     }
 }
 
-__global__ void nb_dtheta_kernel(const float* __restrict__ part_dt, const int* __restrict__ part_flag, int ngroups,
-                                 int64_t G, int C, float* __restrict__ dtheta) {
+__global__ __launch_bounds__(64) void nb_dtheta_kernel(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
+                                                       int ngroups, int64_t G, int C, float* __restrict__ dtheta) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (g >= G) return;
     float s[3] = {0.f, 0.f, 0.f};
-    for (int grp = 0; grp < ngroups; ++grp) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll 8
+        for (int grp = 0; grp < ngroups; ++grp)
             if (part_flag[grp * 3 + p]) s[p] += part_dt[((int64_t)grp * 3 + p) * G + g];
     }
     for (int j = 0; j < C; ++j) {
@@ -382,22 +411,20 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
 
 template <typename TD>
 static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
-    const int64_t G = a.G;
-#define NB_L(NT, NV)                                                                                       \
-    do {                                                                                                   \
-        if (vec) hipLaunchKernelGGL((nb_fwd_bwd_kernel<TD, NT, NV, true>), dim3(ngroups), dim3(NT), 0, st, a); \
-        else hipLaunchKernelGGL((nb_fwd_bwd_kernel<TD, NT, NV, false>), dim3(ngroups), dim3(NT), 0, st, a);    \
+    const size_t lds = (size_t)((a.G + 3) & ~int64_t(3)) * sizeof(float);
+#define NB_L(NT)                                                                                              \
+    do {                                                                                                      \
+        auto kv = nb_fwd_bwd_kernel<TD, NT, true>;                                                             \
+        auto ks = nb_fwd_bwd_kernel<TD, NT, false>;                                                            \
+        if (lds > 48 * 1024) {                                                                                \
+            hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        }                                                                                                     \
+        if (vec) hipLaunchKernelGGL(kv, dim3(ngroups), dim3(NT), lds, st, a);                                  \
+        else hipLaunchKernelGGL(ks, dim3(ngroups), dim3(NT), lds, st, a);                                      \
     } while (0)
-    if (G <= 1024) NB_L(256, 1);
-    else if (G <= 2048) NB_L(256, 2);
-    else if (G <= 4096) NB_L(256, 4);
-    else if (G <= 8192) NB_L(1024, 2);
-    else if (G <= 12288) NB_L(1024, 3);
-    else if (G <= 16384) NB_L(1024, 4);
-    else if (G <= 20480) NB_L(1024, 5);
-    else if (G <= 24576) NB_L(1024, 6);
-    else if (G <= 32768) NB_L(1024, 8);
-    else return 1;
+    if (a.G <= 4096) NB_L(256);
+    else NB_L(1024);
 #undef NB_L
     return 0;
 }
@@ -412,7 +439,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
     C2_CHECK(C >= 1, "NB needs at least one condition column (theta is [G,C])");
     C2_CHECK(ldl >= G && ldx >= G && ldg >= G && lddl >= G, "leading dimension too small");
-    C2_CHECK(G <= 32768, "G > 32768 genes is not supported by the NB kernel yet");
+    C2_CHECK(G <= 40000, "G > 40000 genes is not supported by the NB kernel (its LDS accumulator holds G floats)");
     if (B == 0 || G == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
@@ -428,7 +455,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
-    hipLaunchKernelGGL(nb_dtheta_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part_dt, part_flag, ngroups,
+    hipLaunchKernelGGL(nb_dtheta_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, st, part_dt, part_flag, ngroups,
                        G, C, dtheta);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();

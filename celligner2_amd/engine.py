@@ -183,6 +183,20 @@ class StepEngine:
         ops.linear_fwd(a, w, y, nslab=ns)
         return y
 
+    def _wgrad(self, dy, a, name, alpha=None):
+        """grad[name] = alpha * dy^T a; a short-and-wide weight gradient splits the batch reduction into slabs so
+        that the launch fills the chip, then sums them (deterministic)."""
+        g = self.gbuf(name)
+        N, K = g.shape
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        ns = ops.pick_nslab(tiles, dy.shape[0], bk=64 if dy.dtype != F32 else 32)
+        if ns == 1:
+            ops.linear_wgrad(dy, a, g, alpha=alpha)
+        else:
+            slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
+            ops.linear_wgrad(dy, a, slabs, nslab=ns, alpha=alpha)
+            ops.sum_slabs(slabs, g)
+
     def _block_fwd(self, blk, a, cond, masks, train, save):
         B = a.shape[0]
         y = self._linear_slabs(blk.name, a, blk.w, B)
@@ -207,7 +221,7 @@ class StepEngine:
         ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"], self._ws[blk.name + ".yhat"],
                          self._ws[blk.name + ".rstd"], dh, extra=extra, extra_scale=extra_scale)
         if self.p[blk.w].requires_grad:
-            ops.linear_wgrad(dh, a_in, self.gbuf(blk.w))
+            self._wgrad(dh, a_in, blk.w)
         need_b = blk.b is not None and self.p[blk.b].requires_grad
         need_c = blk.wc is not None and self.p[blk.wc].requires_grad
         if need_b or need_c:
@@ -349,7 +363,7 @@ class StepEngine:
         # ---- decoder output layer
         hw, hb = self.head + ".weight", self.head + ".bias"
         if rq(hw):
-            ops.linear_wgrad(dlogits, self._dlast, self.gbuf(hw), alpha=gr)
+            self._wgrad(dlogits, self._dlast, hw, alpha=gr)
         if rq(hb):
             ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
             ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
@@ -379,7 +393,7 @@ class StepEngine:
             du = self._ws["du"]
             cw, cb = "classifier.classifier.0.weight", "classifier.classifier.0.bias"
             if rq(cw):
-                ops.linear_wgrad(du, self._clast, self.gbuf(cw), alpha=gc)
+                self._wgrad(du, self._clast, cw, alpha=gc)
             if rq(cb):
                 ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
                 ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
@@ -399,7 +413,7 @@ class StepEngine:
         da = self.buf("dheads.da", (2, B, Hk))
         for k, nm in enumerate(("encoder.mean_encoder", "encoder.log_var_encoder")):
             if rq(nm + ".weight"):
-                ops.linear_wgrad(dml[k], henc, self.gbuf(nm + ".weight"))
+                self._wgrad(dml[k], henc, nm + ".weight")
             if rq(nm + ".bias"):
                 ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
                 ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
