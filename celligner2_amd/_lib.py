@@ -55,6 +55,7 @@ _SIGS = {
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "c2_axpy": (i32, [vp, vp, vp, i64, vp]),
+    "c2_dropout_masks": (i32, [vp, i64, f32, C.c_uint64, C.c_uint64, vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

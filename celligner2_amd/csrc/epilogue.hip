@@ -365,6 +365,44 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         for (int j = threadIdx.x; j < P; j += 256) classes_out[r * P + j] = classes[src * P + j];
 }
 
+// Dropout keep-masks for every layer of a step in one launch: Philox-4x32-10 keyed by (seed, offset), 16 mask
+// bytes per counter value.  mask byte = 1 with probability 1-p.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, unsigned thresh8, unsigned long long seed,
+                                    unsigned long long offset) {
+    const int64_t nvec = (n + 15) / 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned r[4];
+        const unsigned long long ctr = offset + (unsigned long long)i;
+        philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0x3c6ef372u, 0xdaa66d2bu, (unsigned)seed,
+                      (unsigned)(seed >> 32), r);
+        u32x4 pk;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (((r[w] >> (8 * b)) & 0xffu) >= thresh8 ? 1u : 0u) << (8 * b);
+            pk[w] = v;
+        }
+        if ((i + 1) * 16 <= n) {
+            *reinterpret_cast<u32x4*>(out + i * 16) = pk;
+        } else {
+            for (int64_t b = i * 16; b < n; ++b) out[b] = (uint8_t)((pk[(b & 15) >> 2] >> (8 * (b & 3))) & 0xffu);
+        }
+    }
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, const float* __restrict__ a_dev, float* __restrict__ y,
                             int64_t n) {
     const float a = a_dev ? *a_dev : 1.f;
@@ -556,6 +594,18 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (float*)xin_out, ldxin, apply_log, vec_ok);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_dropout_masks(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream) {
+    C2_CHECK(out && n >= 0 && aligned16(out), "out must be a 16-byte aligned buffer");
+    C2_CHECK(p_drop >= 0.f && p_drop < 1.f, "bad dropout rate");
+    if (n == 0) return 0;
+    // keep iff byte >= round(256 p): p is quantised to 1/256 (0.05 -> 13/256 = 0.0508); the scale stays 1/(1-p)
+    const unsigned thresh8 = (unsigned)lrintf(p_drop * 256.f);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       thresh8, (unsigned long long)seed, (unsigned long long)offset);
     C2_LAUNCH_CHECK();
     return 0;
 }

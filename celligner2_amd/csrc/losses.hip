@@ -90,8 +90,10 @@ struct NbArgs {
 };
 
 // fast transcendental forms: every argument here is a normal positive float (>= 1e-8)
-__device__ __forceinline__ float flog(float v) { return __logf(v); }
-__device__ __forceinline__ float frcp(float v) { return __frcp_rn(v); }
+// v_log_f32 / v_rcp_f32 / v_exp_f32 directly (1 ulp; no denormal fix-up code, no IEEE division sequence)
+__device__ __forceinline__ float flog(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
+__device__ __forceinline__ float frcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
 
 __device__ __forceinline__ float lgamma_fast(float z) {
     const bool small = z < 8.0f;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
         for_cols(orow, xrow, grow, tth, tk1, tk2, false,
                  [&](int64_t, f32x4 ov, f32x4, unsigned, f32x4, f32x4, f32x4) {
 #pragma unroll
-                     for (int k = 0; k < 4; ++k) sm += __expf(ov[k] - mx);
+                     for (int k = 0; k < 4; ++k) sm += fexp(ov[k] - mx);
                  });
         sm = block_sum<NT>(sm, red);
         const float inv_sum = 1.0f / sm;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
                  [&](int64_t, f32x4 ov, f32x4 xv, unsigned mb, f32x4 t0, f32x4, f32x4) {
 #pragma unroll
                      for (int k = 0; k < 4; ++k) {
-                         const float mu = sf * __expf(ov[k] - mx) * inv_sum;
+                         const float mu = sf * fexp(ov[k] - mx) * inv_sum;
                          const float zt = xv[k] + t0[k];
                          const float v = xv[k] * mu * frcp(mu + eps) - zt * mu * frcp(t0[k] + mu + eps);
                          S += ((mb >> (8 * k)) & 0xffu) ? scale * v : 0.f;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
 #pragma unroll
                      for (int k = 0; k < 4; ++k) {
                          const bool m = (mb >> (8 * k)) & 0xffu;
-                         const float p = __expf(ov[k] - mx) * inv_sum;
+                         const float p = fexp(ov[k] - mx) * inv_sum;
                          const float mu = sf * p;
                          const float th = t0[k], x = xv[k];
                          const float tm = th + mu + eps;
@@ -304,17 +306,181 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void nb_dtheta_kernel(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
-                                                       int ngroups, int64_t G, int C, float* __restrict__ dtheta) {
-    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+// Fast path (16-byte aligned rows, G % 4 == 0): the row's logits, counts and mask live in registers, every load of
+// a pass is in flight at once, and while chunk i of pass 4 is being evaluated the NEXT row's chunk i is already
+// being fetched into the registers chunk i has just released -- HBM latency hides under the log-likelihood maths.
+template <typename TD, int NT, int NV>
+__global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dacc[];
+    __shared__ float red[32];
+    const int tid = threadIdx.x;
+    const int64_t G = a.G;
+    const float eps = 1e-8f;
+    for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
+    int cur_pat = -1, flushed = 0;
+    float loss_acc = 0.f;
+    auto flush = [&](int pat) {
+        __syncthreads();
+        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
+        const bool first = !((flushed >> pat) & 1);
+        for (int64_t c = tid; c < G; c += NT) {
+            dst[c] = first ? dacc[c] : dst[c] + dacc[c];
+            dacc[c] = 0.f;
+        }
+        flushed |= 1 << pat;
+        __syncthreads();
+    };
+    f32x4 ev[NV], xv[NV];
+    unsigned mb[NV];
+    const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int i, int64_t row) {
+        const int64_t c = 4ll * (tid + NT * i);
+        if (c < G) {
+            ev[i] = *reinterpret_cast<const f32x4*>(a.logits + row * a.ldl + c);
+            xv[i] = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + c);
+            mb[i] = *reinterpret_cast<const unsigned*>(a.goodloc + row * a.ldg + c);
+        } else {
+            ev[i] = ninf; xv[i] = zero4; mb[i] = 0u;
+        }
+    };
+    int64_t pref_row = -1;
+    for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
+        int has0 = 0, has1 = 0, bad = 0;
+        for (int j = 0; j < a.C; ++j) {
+            const int64_t v = a.cond[row * a.C + j];
+            has0 |= (v == 0);
+            has1 |= (v == 1);
+            bad |= (v < 0) | (v > 1) | (v >= a.C);
+        }
+        if (bad || (!has0 && !has1)) {
+            if (tid == 0) *a.status = 1;
+            continue;
+        }
+        const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
+        if (pat != cur_pat) {
+            if (cur_pat >= 0) flush(cur_pat);
+            cur_pat = pat;
+        }
+        if (pref_row != row) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) fetch(i, row);
+        }
+        const float sf = a.sizefactor[row];
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float scale = -a.inv_B;
+        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
+        mx = block_max<NT>(mx, red);
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ev[i][k] = fexp(ev[i][k] - mx);
+                sm += ev[i][k];
+            }
+        sm = block_sum<NT>(sm, red);
+        const float inv_sum = 1.0f / sm;
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int64_t c = 4ll * (tid + NT * i);
+            const f32x4 t0 = c < G ? *reinterpret_cast<const f32x4*>(tth + c) : one4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float mu = sf * ev[i][k] * inv_sum;
+                const float zt = xv[i][k] + t0[k];
+                const float v = xv[i][k] * mu * frcp(mu + eps) - zt * mu * frcp(t0[k] + mu + eps);
+                S += ((mb[i] >> (8 * k)) & 0xffu) ? scale * v : 0.f;
+            }
+        }
+        S = block_sum<NT>(S, red);
+        // next row of this workgroup (for the prefetch)
+        const int64_t nrow = row + gridDim.x;
+        TD* drow = reinterpret_cast<TD*>(a.dlogits) + row * a.lddl;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int64_t c0 = 4ll * (tid + NT * i);
+            if (c0 < G) {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tth + c0);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tk1 + c0);
+                const f32x4 t2 = *reinterpret_cast<const f32x4*>(tk2 + c0);
+                float d[4], dt[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool m = (mb[i] >> (8 * k)) & 0xffu;
+                    const float p = ev[i][k] * inv_sum;
+                    const float mu = sf * p;
+                    const float th = t0[k], x = xv[i][k];
+                    const float tm = th + mu + eps;
+                    const float ltm = flog(tm);
+                    const float zt = x + th;
+                    const float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lgamma_fast(zt) - lgamma_fast(x + 1.0f);
+                    const float rtm = frcp(tm);
+                    const float dmu_mu = x * mu * frcp(mu + eps) - zt * mu * rtm;
+                    const float dth = t2[k] - ltm - zt * rtm + digamma_fast(zt);
+                    const float pg = m ? scale * dmu_mu : 0.f;
+                    d[k] = pg - p * S;
+                    dt[k] = m ? scale * th * dth : 0.f;
+                    loss_acc += m ? ll : 0.f;
+                }
+                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c0);
+                acc[0] += dt[0]; acc[1] += dt[1]; acc[2] += dt[2]; acc[3] += dt[3];
+                *reinterpret_cast<f32x4*>(dacc + c0) = acc;
+                if (sizeof(TD) == 4) {
+                    f32x4 o = {d[0], d[1], d[2], d[3]};
+                    *reinterpret_cast<f32x4*>(drow + c0) = o;
+                } else {
+                    u32x2 pk;
+                    pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
+                    pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
+                    *reinterpret_cast<u32x2*>(drow + c0) = pk;
+                }
+            }
+            if (nrow < a.B) fetch(i, nrow);  // registers of chunk i are free: start the next row's loads
+        }
+        pref_row = nrow < a.B ? nrow : -1;
+    }
+    if (cur_pat >= 0) flush(cur_pat);
+    loss_acc = block_sum<NT>(loss_acc, red);
+    if (tid == 0) {
+        a.part_loss[blockIdx.x] = -a.inv_B * loss_acc;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.part_flag[blockIdx.x * 3 + p] = (flushed >> p) & 1;
+    }
+}
+
+// dtheta reduction, stage 1: partial sums over slices of the workgroup partials
+constexpr int kDthSlices = 32;
+__global__ __launch_bounds__(256) void nb_dtheta_stage1(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
+                                                        int ngroups, int64_t G, float* __restrict__ part2 /*[S][3][G]*/) {
+    const int64_t g = blockIdx.x * 256ll + threadIdx.x;
+    const int sl = blockIdx.y;
+    const int per = (ngroups + kDthSlices - 1) / kDthSlices;
+    const int g0 = sl * per, g1 = min(ngroups, g0 + per);
+    if (g >= G) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float s = 0.f;
+        for (int grp = g0; grp < g1; ++grp)
+            if (part_flag[grp * 3 + p]) s += part_dt[((int64_t)grp * 3 + p) * G + g];
+        part2[((int64_t)sl * 3 + p) * G + g] = s;
+    }
+}
+__global__ __launch_bounds__(256) void nb_dtheta_stage2(const float* __restrict__ part2, int64_t G, int C,
+                                                        float* __restrict__ dtheta) {
+    const int64_t g = blockIdx.x * 256ll + threadIdx.x;
     if (g >= G) return;
     float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 3; ++p)
 #pragma unroll 8
-        for (int grp = 0; grp < ngroups; ++grp)
-            if (part_flag[grp * 3 + p]) s[p] += part_dt[((int64_t)grp * 3 + p) * G + g];
-    }
+        for (int sl = 0; sl < kDthSlices; ++sl) s[p] += part2[((int64_t)sl * 3 + p) * G + g];
     for (int j = 0; j < C; ++j) {
         float v = 0.f;
         if (j == 0) v = s[0] + s[2];
@@ -406,7 +572,7 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     (void)C;
     const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
     // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
-    return (size_t)(9 * G + ng * 3 * G + ng * 3 + ng + 64);
+    return (size_t)(9 * G + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G);
 }
 
 template <typename TD>
@@ -417,15 +583,34 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
         auto kv = nb_fwd_bwd_kernel<TD, NT, true>;                                                             \
         auto ks = nb_fwd_bwd_kernel<TD, NT, false>;                                                            \
         if (lds > 48 * 1024) {                                                                                \
-            hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         }                                                                                                     \
         if (vec) hipLaunchKernelGGL(kv, dim3(ngroups), dim3(NT), lds, st, a);                                  \
         else hipLaunchKernelGGL(ks, dim3(ngroups), dim3(NT), lds, st, a);                                      \
     } while (0)
+#define NB_F(NT, NV)                                                                                          \
+    do {                                                                                                      \
+        auto kf = nb_rowreg_kernel<TD, NT, NV>;                                                                \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), lds, st, a);                                           \
+        return 0;                                                                                             \
+    } while (0)
+    if (vec) {
+        const int64_t G = a.G;
+        if (G <= 1024) NB_F(256, 1);
+        if (G <= 2048) NB_F(256, 2);
+        if (G <= 4096) NB_F(256, 4);
+        if (G <= 8192) NB_F(1024, 2);
+        if (G <= 12288) NB_F(1024, 3);
+        if (G <= 16384) NB_F(1024, 4);
+        if (G <= 20480) NB_F(1024, 5);
+        if (G <= 24576) NB_F(1024, 6);
+    }
     if (a.G <= 4096) NB_L(256);
     else NB_L(1024);
 #undef NB_L
+#undef NB_F
     return 0;
 }
 
@@ -455,8 +640,10 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
-    hipLaunchKernelGGL(nb_dtheta_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, st, part_dt, part_flag, ngroups,
-                       G, C, dtheta);
+    float* part2 = part_loss + ngroups + 32;
+    hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
+                       ngroups, G, part2);
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;

@@ -315,13 +315,24 @@ class Celligner2(nn.Module):
                 for n, s in shapes[nh:] + cls_shapes:
                     masks[n] = cpu_mask(s)
         else:
-            if training:
-                for n, s in shapes[:nh]:
-                    masks[n] = (torch.rand(s, device=device) >= self.dr_rate).to(torch.uint8)
             eps = torch.randn(B, self.latent_dim, device=device)
-            if training:
-                for n, s in shapes[nh:] + cls_shapes:
-                    masks[n] = (torch.rand(s, device=device) >= self.dr_rate).to(torch.uint8)
+            allshapes = shapes + cls_shapes
+            if training and allshapes:
+                # every mask of the step from one Philox launch into one flat buffer (16-byte aligned slices)
+                sizes = [(s[0] * s[1] + 15) // 16 * 16 for _, s in allshapes]
+                total = sum(sizes)
+                flat = self.__dict__.get("_mask_buf")
+                if flat is None or flat.numel() != total or flat.device != device:
+                    flat = torch.empty(total, dtype=torch.uint8, device=device)
+                    self.__dict__["_mask_buf"] = flat
+                    self.__dict__["_mask_seed"] = torch.initial_seed()
+                    self.__dict__["_mask_offset"] = 0
+                ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"], self.__dict__["_mask_offset"])
+                self.__dict__["_mask_offset"] += total // 16
+                o = 0
+                for (n, s), sz in zip(allshapes, sizes):
+                    masks[n] = flat[o:o + s[0] * s[1]].view(s)
+                    o += sz
         return eps, masks
 
     # ------------------------------------------------------------------ the reference's API

@@ -276,3 +276,11 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
 def axpy(x, a_dev, y):
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib.c2_axpy(ptr(x), ptr(a_dev), ptr(y), x.numel(), stream()))
+
+
+def dropout_masks(out, p_drop, seed, offset):
+    """Fill the flat uint8 buffer `out` with keep-masks (1 = keep)."""
+    L.require_gpu(out)
+    assert out.dtype == torch.uint8 and out.is_contiguous()
+    check(lib.c2_dropout_masks(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), int(offset), stream()))
+    return out

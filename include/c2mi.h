@@ -174,6 +174,11 @@ int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefact
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
                    int xin_dtype, int64_t ldxin, int apply_log, void* stream);
 
+/* Dropout keep-masks (nn.Dropout of modules.py:309-312,426-431,458-461,579-582,607-610) for all layers of a step in
+ * one launch: out[i] = 1 with probability 1-p (Philox-4x32-10 keyed by seed, counter offset + i/16).  The stream of
+ * random numbers differs from torch's generator by construction; parity tests inject recorded masks instead. */
+int c2_dropout_masks(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
 /* y[i] = a*x[i] + y[i] (a = *a_dev), fp32; used to merge loss-branch gradients. */
 int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
 

@@ -342,3 +342,17 @@ def test_prep_and_gather():
     out = torch.empty(N, G, device=DEV)
     ops.prep_input(T(X), out, True)
     assert rel(out, np.log(1 + X.astype(np.float64))) < 1e-6
+
+
+def test_dropout_masks_rate_and_determinism():
+    ops = _ops()
+    n = 1_000_003
+    a = torch.empty(n, dtype=torch.uint8, device=DEV)
+    b = torch.empty(n, dtype=torch.uint8, device=DEV)
+    ops.dropout_masks(a, 0.05, 1234, 0)
+    ops.dropout_masks(b, 0.05, 1234, 0)
+    assert torch.equal(a, b) and set(a.unique().tolist()) <= {0, 1}
+    keep = a.float().mean().item()
+    assert abs(keep - (1 - 13 / 256)) < 2e-3  # p quantised to 1/256
+    ops.dropout_masks(b, 0.05, 1234, n // 16 + 1)
+    assert not torch.equal(a, b)
