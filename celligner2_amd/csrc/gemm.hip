@@ -24,26 +24,40 @@ struct GemmArgs {
     int M, N, R, r_per_split;
 };
 
+struct x3_t {};  // tag: fp32 operands in memory, multiplied as three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+
 template <typename T>
 struct Cfg;
 template <>
 struct Cfg<bf16_t> {
-    static constexpr int BK = 64, VEC = 8;
+    typedef bf16_t GT;  // element type in global memory
+    typedef bf16_t LT;  // element type in LDS
+    static constexpr int BK = 64, VEC = 8, NTILE = 1;
     static constexpr int S_RC = 72;   // [128][72] bf16: 144-B rows, ds_read_b128 conflict-free
     static constexpr int S_XC = 160;  // [64][160] bf16: 320-B rows, 4 k-rows hit 4 distinct 64-B bank groups
 };
 template <>
 struct Cfg<float> {
-    static constexpr int BK = 32, VEC = 4;
+    typedef float GT;
+    typedef float LT;
+    static constexpr int BK = 32, VEC = 4, NTILE = 1;
     static constexpr int S_RC = 33;   // [128][33] f32
     static constexpr int S_XC = 132;  // [32][132] f32
+};
+template <>
+struct Cfg<x3_t> {
+    typedef float GT;
+    typedef bf16_t LT;
+    static constexpr int BK = 32, VEC = 4, NTILE = 2;  // hi and lo bf16 tiles per operand
+    static constexpr int S_RC = 40;   // [128][40] bf16: 80-B rows
+    static constexpr int S_XC = 160;  // [32][160] bf16
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
 
 template <typename T, bool RC>
 __host__ __device__ constexpr int tile_elems() {
-    return RC ? BM * Cfg<T>::S_RC : Cfg<T>::BK * Cfg<T>::S_XC;
+    return ((RC ? BM * Cfg<T>::S_RC : Cfg<T>::BK * Cfg<T>::S_XC) + 7) & ~7;
 }
 
 // 16 bytes of operand data held in registers between the global load and the LDS write
@@ -52,8 +66,9 @@ struct Vec16 {
 };
 
 template <typename T, bool RC, bool ALIGNED>
-__device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ld, int x0, int xtot, int r0,
-                                          int rend, Vec16 (&regs)[4]) {
+__device__ __forceinline__ void load_tile(const typename Cfg<T>::GT* __restrict__ base, int64_t ld, int x0, int xtot,
+                                          int r0, int rend, Vec16 (&regs)[4]) {
+    typedef typename Cfg<T>::GT GT;
     constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
     constexpr int VPR = RC ? (BK / VEC) : (BM / VEC);  // vectors per LDS row
 #pragma unroll
@@ -81,9 +96,9 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ld
             val = *reinterpret_cast<const u32x4*>(base + off);
         } else if (any) {
             const int lim = RC ? (rend - r) : (xtot - x);
-            T tmp[VEC];
+            GT tmp[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) tmp[e] = (e < lim) ? base[off + e] : T(0);
+            for (int e = 0; e < VEC; ++e) tmp[e] = (e < lim) ? base[off + e] : GT(0);
             val = *reinterpret_cast<u32x4*>(tmp);
         }
         regs[i].v = val;
@@ -91,7 +106,7 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ld
 }
 
 template <typename T, bool RC>
-__device__ __forceinline__ void store_tile(T* __restrict__ lds, const Vec16 (&regs)[4]) {
+__device__ __forceinline__ void store_tile(typename Cfg<T>::LT* __restrict__ lds, const Vec16 (&regs)[4]) {
     constexpr int VEC = Cfg<T>::VEC, BK = Cfg<T>::BK;
     constexpr int VPR = RC ? (BK / VEC) : (BM / VEC);
     constexpr int S = RC ? Cfg<T>::S_RC : Cfg<T>::S_XC;
@@ -99,28 +114,45 @@ __device__ __forceinline__ void store_tile(T* __restrict__ lds, const Vec16 (&re
     for (int i = 0; i < 4; ++i) {
         const int v = threadIdx.x + NT * i;
         const int row = v / VPR, cv = v % VPR;
-        T* dst = lds + row * S + cv * VEC;
-        if (sizeof(T) == 4 && RC) {  // stride 33: scalar stores
-            const float* s = reinterpret_cast<const float*>(&regs[i].v);
-            float* d = reinterpret_cast<float*>(dst);
-            d[0] = s[0];
-            d[1] = s[1];
-            d[2] = s[2];
-            d[3] = s[3];
+        if constexpr (Cfg<T>::NTILE == 2) {  // split each fp32 into hi + lo bf16, two tiles
+            const float* f = reinterpret_cast<const float*>(&regs[i].v);
+            bf16_t hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = f2bf(f[e]);
+                lo[e] = f2bf(f[e] - bf2f(hi[e]));
+            }
+            bf16_t* dst = lds + row * S + cv * VEC;
+            u32x2 ph, pl;
+            ph[0] = (unsigned)hi[0] | ((unsigned)hi[1] << 16);
+            ph[1] = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+            pl[0] = (unsigned)lo[0] | ((unsigned)lo[1] << 16);
+            pl[1] = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+            *reinterpret_cast<u32x2*>(dst) = ph;
+            *reinterpret_cast<u32x2*>(dst + tile_elems<T, RC>()) = pl;
         } else {
-            *reinterpret_cast<u32x4*>(dst) = regs[i].v;
+            typename Cfg<T>::LT* dst = lds + row * S + cv * VEC;
+            if (sizeof(typename Cfg<T>::LT) == 4 && RC) {  // stride 33: scalar stores
+                const float* sf = reinterpret_cast<const float*>(&regs[i].v);
+                float* d = reinterpret_cast<float*>(dst);
+                d[0] = sf[0];
+                d[1] = sf[1];
+                d[2] = sf[2];
+                d[3] = sf[3];
+            } else {
+                *reinterpret_cast<u32x4*>(dst) = regs[i].v;
+            }
         }
     }
 }
 
 // bf16 fragment (8 values along the reduction for row/col x = xt + (lane&31), k = 8*(lane>>5)+j)
-template <bool RC>
+template <bool RC, int S>
 __device__ __forceinline__ bf16x8 read_frag_bf16(const bf16_t* lds, int xt, int r0, int lane) {
     if (RC) {
-        const bf16_t* p = lds + (xt + (lane & 31)) * Cfg<bf16_t>::S_RC + r0 + 8 * (lane >> 5);
+        const bf16_t* p = lds + (xt + (lane & 31)) * S + r0 + 8 * (lane >> 5);
         return *reinterpret_cast<const bf16x8*>(p);
     } else {
-        constexpr int S = Cfg<bf16_t>::S_XC;
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3, h = lane >> 5;
         const bf16_t* p = lds + (r0 + 8 * h + q) * S + xt + 16 * (g & 1) + 4 * p4;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -141,10 +173,14 @@ __device__ __forceinline__ float read_frag_f32(const float* lds, int xt, int r, 
 
 template <typename T, bool A_RC, bool B_RC, bool ALIGNED>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
+    typedef typename Cfg<T>::GT GT;
+    typedef typename Cfg<T>::LT LT;
     constexpr int BK = Cfg<T>::BK;
+    constexpr int SA = A_RC ? Cfg<T>::S_RC : Cfg<T>::S_XC;
+    constexpr int SB = B_RC ? Cfg<T>::S_RC : Cfg<T>::S_XC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* ldsA = reinterpret_cast<T*>(smem);
-    T* ldsB = ldsA + ((tile_elems<T, A_RC>() + 7) & ~7);
+    LT* ldsA = reinterpret_cast<LT*>(smem);
+    LT* ldsB = ldsA + Cfg<T>::NTILE * tile_elems<T, A_RC>();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -152,8 +188,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
     const int split = blockIdx.z;
     const int rbeg = split * a.r_per_split;
     const int rend = min(a.R, rbeg + a.r_per_split);
-    const T* A = reinterpret_cast<const T*>(a.A);
-    const T* B = reinterpret_cast<const T*>(a.B);
+    const GT* A = reinterpret_cast<const GT*>(a.A);
+    const GT* B = reinterpret_cast<const GT*>(a.B);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -178,21 +214,44 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
             load_tile<T, A_RC, ALIGNED>(A, a.lda, m0, a.M, r0, rend, ra);
             load_tile<T, B_RC, ALIGNED>(B, a.ldb, n0, a.N, r0, rend, rb);
         }
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(LT) == 2 && Cfg<T>::NTILE == 1) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 bf16x8 fa[2], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    fa[i] = read_frag_bf16<A_RC>(reinterpret_cast<const bf16_t*>(ldsA), wm * 64 + i * 32, ks * 16, lane);
+                for (int i = 0; i < 2; ++i) fa[i] = read_frag_bf16<A_RC, SA>(ldsA, wm * 64 + i * 32, ks * 16, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    fb[j] = read_frag_bf16<B_RC>(reinterpret_cast<const bf16_t*>(ldsB), wn * 64 + j * 32, ks * 16, lane);
+                for (int j = 0; j < 2; ++j) fb[j] = read_frag_bf16<B_RC, SB>(ldsB, wn * 64 + j * 32, ks * 16, lane);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (Cfg<T>::NTILE == 2) {
+            const bf16_t* aLo = ldsA + tile_elems<T, A_RC>();
+            const bf16_t* bLo = ldsB + tile_elems<T, B_RC>();
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fah[i] = read_frag_bf16<A_RC, SA>(ldsA, wm * 64 + i * 32, ks * 16, lane);
+                    fal[i] = read_frag_bf16<A_RC, SA>(aLo, wm * 64 + i * 32, ks * 16, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fbh[j] = read_frag_bf16<B_RC, SB>(ldsB, wn * 64 + j * 32, ks * 16, lane);
+                    fbl[j] = read_frag_bf16<B_RC, SB>(bLo, wn * 64 + j * 32, ks * 16, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                    }
             }
         } else {
 #pragma unroll 4
@@ -240,8 +299,7 @@ template <typename T, bool A_RC, bool B_RC>
 static int launch_gemm(const GemmArgs& a, int nslab, hipStream_t stream) {
     constexpr int VEC = Cfg<T>::VEC;
     const bool aligned = aligned16(a.A) && aligned16(a.B) && (a.lda % VEC == 0) && (a.ldb % VEC == 0);
-    const size_t lds = (((size_t)tile_elems<T, A_RC>() + 7) & ~size_t(7)) * sizeof(T) +
-                       (size_t)tile_elems<T, B_RC>() * sizeof(T);
+    const size_t lds = (size_t)Cfg<T>::NTILE * (tile_elems<T, A_RC>() + tile_elems<T, B_RC>()) * sizeof(typename Cfg<T>::LT);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nslab);
     if (aligned)
         hipLaunchKernelGGL((gemm_kernel<T, A_RC, B_RC, true>), grid, dim3(NT), lds, stream, a);
@@ -250,20 +308,21 @@ static int launch_gemm(const GemmArgs& a, int nslab, hipStream_t stream) {
     return 0;
 }
 
+template <typename T>
+static int gemm_layout(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+    if (layout == 0) return launch_gemm<T, true, true>(a, nslab, stream);
+    if (layout == 1) return launch_gemm<T, true, false>(a, nslab, stream);
+    return launch_gemm<T, false, false>(a, nslab, stream);
+}
+
 static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream_t stream) {
-    const int BK = dtype == C2_BF16 ? Cfg<bf16_t>::BK : Cfg<float>::BK;
+    const int BK = dtype == C2_BF16 ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
     int64_t per = (a.R + nslab - 1) / nslab;
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
-    if (dtype == C2_BF16) {
-        if (layout == 0) return launch_gemm<bf16_t, true, true>(a, nslab, stream);
-        if (layout == 1) return launch_gemm<bf16_t, true, false>(a, nslab, stream);
-        return launch_gemm<bf16_t, false, false>(a, nslab, stream);
-    } else {
-        if (layout == 0) return launch_gemm<float, true, true>(a, nslab, stream);
-        if (layout == 1) return launch_gemm<float, true, false>(a, nslab, stream);
-        return launch_gemm<float, false, false>(a, nslab, stream);
-    }
+    if (dtype == C2_BF16) return gemm_layout<bf16_t>(layout, a, nslab, stream);
+    if (dtype == C2_F32X3) return gemm_layout<x3_t>(layout, a, nslab, stream);
+    return gemm_layout<float>(layout, a, nslab, stream);
 }
 
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int64_t stride, float* __restrict__ out,
@@ -280,7 +339,7 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int
 using namespace c2;
 
 static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) {
-    return (dtype == C2_F32 || dtype == C2_BF16) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
+    return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
            M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
 

@@ -189,20 +189,34 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
         ni[e] = ok ? norms[gi[e]] : 0.f;
         pi[e] = ok ? part_id[gi[e]] : -1;
     }
+    const bool vec_ok = (sizeof(TF) == 4) && ((ldf & 3) == 0) && ((D & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(f) & 15) == 0);
     auto stage = [&](float* dst, int64_t grow0, int64_t nrows_total, int d0) {
-        // 32 rows x 64 cols, lane covers (row = k*? ...) coalesced: 16 lanes per row (4 floats each)
+        // 32 rows x 64 cols: 16 lanes per row, 4 consecutive features each (one 16-byte load when aligned)
+        f32x4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int idx = lane + 64 * k;  // 0..511
             const int r = idx >> 4, c4 = (idx & 15) * 4;
             const int64_t gr = grow0 + r;
+            const int d = d0 + c4;
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gr < nrows_total && d < D) {
+                if (vec_ok) {
+                    v[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(f) + gr * ldf + d);
+                } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = d0 + c4 + q;
-                float v = 0.f;
-                if (gr < nrows_total && d < D) v = ld_as_f32<TF>(f + gr * ldf + d);
-                dst[r * LDT + c4 + q] = v;
+                    for (int q = 0; q < 4; ++q)
+                        if (d + q < D) v[k][q] = ld_as_f32<TF>(f + gr * ldf + d + q);
+                }
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = lane + 64 * k;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[r * LDT + c4 + q] = v[k][q];
         }
     };
 
@@ -249,13 +263,21 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
             if (gi[e] == gj) d = 0.f;  // exact self distance
             float S = 0.f, Wp = 0.f;
             if (w != 0.f) {
-#pragma unroll
-                for (int k = 0; k < 19; ++k) {
-                    const float bk = 1.0f / (2.0f * c_mmd_alphas[k]);
-                    const float ex = __expf(-bk * d);
-                    S += ex;
-                    Wp += 2.f * bk * ex;
-                }
+                // beta_k = 1/(2 alpha_k) folded at compile time in fp32, as the reference forms it (losses.py:156);
+                // exp(-beta d) = exp2(-beta log2(e) d) on v_exp_f32
+#define C2_MMD_TERM(ALPHA)                                                      \
+    {                                                                           \
+        constexpr float bk = 1.0f / (2.0f * (ALPHA));                           \
+        constexpr float ck = -bk * 1.4426950408889634f;                         \
+        const float ex = __builtin_amdgcn_exp2f(ck * d);                        \
+        S += ex;                                                                \
+        Wp = fmaf(2.f * bk, ex, Wp);                                            \
+    }
+                C2_MMD_TERM(1e-6f) C2_MMD_TERM(1e-5f) C2_MMD_TERM(1e-4f) C2_MMD_TERM(1e-3f) C2_MMD_TERM(1e-2f)
+                C2_MMD_TERM(1e-1f) C2_MMD_TERM(1.f) C2_MMD_TERM(5.f) C2_MMD_TERM(10.f) C2_MMD_TERM(15.f)
+                C2_MMD_TERM(20.f) C2_MMD_TERM(25.f) C2_MMD_TERM(30.f) C2_MMD_TERM(35.f) C2_MMD_TERM(100.f)
+                C2_MMD_TERM(1e3f) C2_MMD_TERM(1e4f) C2_MMD_TERM(1e5f) C2_MMD_TERM(1e6f)
+#undef C2_MMD_TERM
             }
             lacc += w * S;
             // a self pair adds K = 19 to the loss but no gradient (f_i - f_i = 0): drop its 1e6-scale weight,

@@ -39,6 +39,7 @@ class StepEngine:
         self.p = params
         self.precision = precision
         self.T = F32 if precision == "fp32" else torch.bfloat16
+        self.x3 = precision == "bf16"  # narrow fp32-operand GEMMs run as 3 bf16 MFMA products in bf16 mode
         self.dev = next(iter(params.values())).device
         self._ws = {}
         self._shadow = {}
@@ -180,7 +181,7 @@ class StepEngine:
         tiles = ((B + 127) // 128) * ((N + 127) // 128)
         ns = ops.pick_nslab(tiles, K)
         y = self.buf(key + ".Y", (ns, B, N))
-        ops.linear_fwd(a, w, y, nslab=ns)
+        ops.linear_fwd(a, w, y, nslab=ns, x3=self.x3)
         return y
 
     def _wgrad(self, dy, a, name, alpha=None):
@@ -191,10 +192,10 @@ class StepEngine:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         ns = ops.pick_nslab(tiles, dy.shape[0], bk=64 if dy.dtype != F32 else 32)
         if ns == 1:
-            ops.linear_wgrad(dy, a, g, alpha=alpha)
+            ops.linear_wgrad(dy, a, g, alpha=alpha, x3=self.x3)
         else:
             slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
-            ops.linear_wgrad(dy, a, slabs, nslab=ns, alpha=alpha)
+            ops.linear_wgrad(dy, a, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
 
     def _block_fwd(self, blk, a, cond, masks, train, save):
@@ -237,7 +238,7 @@ class StepEngine:
             tiles = ((B + 127) // 128) * ((K + 127) // 128)
             ns = ops.pick_nslab(tiles, H)
             out_slabs = self.buf(blk.name + ".da", (ns, B, K))
-        ops.linear_dgrad(dh, w, out_slabs, nslab=out_slabs.shape[0])
+        ops.linear_dgrad(dh, w, out_slabs, nslab=out_slabs.shape[0], x3=self.x3)
         return out_slabs
 
     # ------------------------------------------------------------------ forward
@@ -278,9 +279,9 @@ class StepEngine:
         L = cfg["latent"]
         mulv = self.buf("mulv", (2, B, L))
         ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
-                       bias=self.p["encoder.mean_encoder.bias"].detach())
+                       bias=self.p["encoder.mean_encoder.bias"].detach(), x3=self.x3)
         ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
-                       bias=self.p["encoder.log_var_encoder.bias"].detach())
+                       bias=self.p["encoder.log_var_encoder.bias"].detach(), x3=self.x3)
         z32 = self.buf("z32", (B, L))
         red_ws = self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),))
         zdt = self.dec[0].gt
@@ -296,7 +297,7 @@ class StepEngine:
         self._dlast = d
         y1 = self._ws["dec0.act"]
         logits = self.buf("logits", (B, G))
-        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach())
+        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach(), x3=self.x3)
         # ---- reconstruction loss (+ its unit-upstream gradient)
         dlogits = self.buf("dlogits", (B, G), self.head_t)
         if cfg["recon_loss"] == "nb":
@@ -322,7 +323,7 @@ class StepEngine:
             if P > 0:
                 u = self.buf("u", (B, P))
                 ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
-                               bias=self.p["classifier.classifier.0.bias"].detach())
+                               bias=self.p["classifier.classifier.0.bias"].detach(), x3=self.x3)
                 du = self.buf("du", (B, P), self.gemm_dtype("classifier.classifier.0.weight"))
                 ops.classifier_loss(u, classes, cfg["betaclass"], losses[3:4], du, red_ws)
         # ---- MMD over the (global) batch
@@ -372,7 +373,7 @@ class StepEngine:
         tiles = ((B + 127) // 128) * ((H1 + 127) // 128)
         ns = ops.pick_nslab(tiles, G)
         dd = self.buf("dhead.da", (ns, B, H1))
-        ops.linear_dgrad(dlogits, w, dd, nslab=ns, alpha=gr)
+        ops.linear_dgrad(dlogits, w, dd, nslab=ns, alpha=gr, x3=self.x3)
         if cfg["recon_loss"] == "nb" and rq("theta"):
             gt = self.gbuf("theta")
             gt.zero_()
@@ -398,7 +399,7 @@ class StepEngine:
                 ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
                 ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
             dc = self.buf("dcls.da", (1, B, self._clast.shape[1]))
-            ops.linear_dgrad(du, self.weight(cw), dc, alpha=gc)
+            ops.linear_dgrad(du, self.weight(cw), dc, alpha=gc, x3=self.x3)
             for i in range(len(self.cls) - 1, 0, -1):
                 dc = self._block_bwd(self.cls[i], dc, self._cls_in[i], None, masks, True)
             self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[1:2])
@@ -417,7 +418,7 @@ class StepEngine:
             if rq(nm + ".bias"):
                 ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
                 ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
-            ops.linear_dgrad(dml[k], self.weight(nm + ".weight"), da[k:k + 1])
+            ops.linear_dgrad(dml[k], self.weight(nm + ".weight"), da[k:k + 1], x3=self.x3)
         # ---- encoder blocks
         need = self._first_trainable_enc()
         for i in range(len(self.enc) - 1, -1, -1):
@@ -456,9 +457,9 @@ class StepEngine:
         L = cfg["latent"]
         mulv = self.buf("mulv", (2, B, L))
         ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
-                       bias=self.p["encoder.mean_encoder.bias"].detach())
+                       bias=self.p["encoder.mean_encoder.bias"].detach(), x3=self.x3)
         ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
-                       bias=self.p["encoder.log_var_encoder.bias"].detach())
+                       bias=self.p["encoder.log_var_encoder.bias"].detach(), x3=self.x3)
         z = None
         if eps is not None:
             z = self.buf("z32", (B, L))
@@ -476,7 +477,7 @@ class StepEngine:
         u = self.buf("u", (z.shape[0], P))
         if P > 0:
             ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
-                           bias=self.p["classifier.classifier.0.bias"].detach())
+                           bias=self.p["classifier.classifier.0.bias"].detach(), x3=self.x3)
         return u
 
     def decode(self, z, cond):
@@ -487,7 +488,7 @@ class StepEngine:
         B = z.shape[0]
         G = self.cfg["input_dim"]
         logits = self.buf("logits", (B, G))
-        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach())
+        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach(), x3=self.x3)
         return logits, self._ws["dec0.act"]
 
     def check_status(self):

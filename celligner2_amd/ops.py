@@ -16,7 +16,7 @@ class _GemmTimer:
     """Event pair on the launch stream around one gene-width GEMM (only while bench.py asks for it)."""
 
     def __init__(self, M, N, K):
-        self.on = PROFILE_GEMM is not None and max(M, N, K) >= 2048 and min(M, N, K) >= 64
+        self.on = PROFILE_GEMM is not None and max(N, K) >= 2048 and min(M, N, K) >= 64  # weight is gene-width
         if self.on:
             self.flops = 2.0 * M * N * K
             self.s = torch.cuda.Event(enable_timing=True)
@@ -32,6 +32,10 @@ class _GemmTimer:
             self.e.record()
             PROFILE_GEMM.append((self.flops, self.s, self.e))
         return False
+
+
+def _gemm_code(dtype, x3):
+    return 2 if (x3 and dtype == torch.float32) else dt_code(dtype)
 
 
 def _row_major(t, name):
@@ -55,7 +59,7 @@ def prep_input(x, out, apply_log):
     return out
 
 
-def linear_fwd(a, w, y, bias=None, nslab=1):
+def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
     """y[s] = a @ w.T (+bias).  y: [M,N] or [nslab,M,N] fp32."""
     L.require_gpu(a, w, y)
     M, K = a.shape
@@ -66,12 +70,12 @@ def linear_fwd(a, w, y, bias=None, nslab=1):
     ss = y.stride(0) if y.dim() == 3 else 0
     assert (y.dim() == 3 and y.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), dt_code(a.dtype), M, N, K,
+        check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), _gemm_code(a.dtype, x3), M, N, K,
                                 ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
     return y
 
 
-def linear_dgrad(dy, w, da, nslab=1, alpha=None):
+def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     """da[s] = alpha * dy @ w.   dy [M,N], w [N,K], da [M,K] or [nslab,M,K]."""
     L.require_gpu(dy, w, da)
     M, N = dy.shape
@@ -82,12 +86,12 @@ def linear_dgrad(dy, w, da, nslab=1, alpha=None):
     ss = da.stride(0) if da.dim() == 3 else 0
     assert (da.dim() == 3 and da.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), dt_code(dy.dtype), M, N,
+        check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), _gemm_code(dy.dtype, x3), M, N,
                                   K, ptr(da), _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
     return da
 
 
-def linear_wgrad(dy, a, dw, nslab=1, alpha=None):
+def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False):
     """dw[s] = alpha * dy.T @ a.   dy [M,N], a [M,K], dw [N,K] or [nslab,N,K]."""
     L.require_gpu(dy, a, dw)
     M, N = dy.shape
@@ -98,7 +102,7 @@ def linear_wgrad(dy, a, dw, nslab=1, alpha=None):
     ss = dw.stride(0) if dw.dim() == 3 else 0
     assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), dt_code(dy.dtype), M, N,
+        check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), _gemm_code(dy.dtype, x3), M, N,
                                   K, ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
     return dw
 

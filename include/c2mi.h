@@ -30,6 +30,10 @@ extern "C" {
 
 #define C2_F32 0
 #define C2_BF16 1
+/* GEMM entry points only: fp32 operands in memory, each split in-kernel into hi+lo bf16 and multiplied as three
+ * bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative product error at 3/16 of the
+ * fp32-MFMA cost (gfx950 has no TF32).  Used for the narrow hidden-layer GEMMs of bf16 mode. */
+#define C2_F32X3 2
 
 #define C2_MMD_MAX_PARTS 64 /* max distinct condition rows per batch for the MMD partition */
 

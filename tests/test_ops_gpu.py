@@ -356,3 +356,24 @@ def test_dropout_masks_rate_and_determinism():
     assert abs(keep - (1 - 13 / 256)) < 2e-3  # p quantised to 1/256
     ops.dropout_masks(b, 0.05, 1234, n // 16 + 1)
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 1024), (300, 64, 515), (4096, 100, 70)])
+def test_linear_bf16x3_mode(M, N, K):
+    """fp32 operands multiplied as hi*hi + hi*lo + lo*hi bf16 MFMA products: ~2^-16 relative product error."""
+    ops = _ops()
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    ta, tw, tdy = T(a), T(w), T(dy)
+    a64, w64, dy64 = a.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(ta, tw, y, x3=True)
+    assert rel(y, a64 @ w64.T) < 5e-5
+    da = torch.empty(M, K, device=DEV)
+    ops.linear_dgrad(tdy, tw, da, x3=True)
+    assert rel(da, dy64 @ w64) < 5e-5
+    dw = torch.empty(2, N, K, device=DEV)
+    ops.linear_wgrad(tdy, ta, dw, nslab=2, x3=True)
+    assert rel(dw.sum(0), dy64.T @ a64) < 5e-5
