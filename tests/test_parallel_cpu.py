@@ -1,0 +1,104 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel host logic: sharding, all-gather order, bucket all-reduce,
+and the identity the design rests on -- per-rank losses/gradients normalised by the GLOBAL batch, with the MMD
+gradient of a rank's own rows taken from (own rows x all rows), SUM to the single-process step.  The per-rank
+compute in this test is the CPU oracle (test infrastructure); the product's kernels are covered on the GPU by
+tests/test_parallel_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from celligner2_amd.parallel import DataParallelStep
+    from oracle import c2_oracle as orc
+    comm = DataParallelStep()
+    assert comm.shard(10) == ((0, 5) if rank == 0 else (5, 10))
+    assert comm.shard(11) == ((0, 5) if rank == 0 else (5, 11))
+    # all-gather keeps rank order
+    feat = torch.full((3, 2), float(rank))
+    cond = torch.full((3, 2), rank, dtype=torch.int64)
+    fa, ca = comm.allgather_rows(feat, cond)
+    assert fa[:3].eq(0).all() and fa[3:].eq(1).all() and ca[3:].eq(1).all()
+    # bucket all-reduce = SUM
+    g = torch.arange(6, dtype=torch.float32) * (rank + 1)
+    comm.allreduce_bucket_async(g)
+    comm.wait_all()
+    assert torch.equal(g, torch.arange(6, dtype=torch.float32) * 3)
+    # the decomposition identity, with the oracle as the per-rank compute
+    rng = np.random.default_rng(0)
+    B, G, C, P, L = 16, 40, 2, 3, 4
+    cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=[12, 8], latent_dim=L, n_conditions=C, n_predictors=P,
+                  recon_loss="nb", use_mmd=False)
+    params = orc.init_params(cfg, 0, np.float64)
+    x = rng.poisson(3.0, (B, G)).astype(np.float64)
+    condm = np.zeros((B, C), np.int64)
+    condm[np.arange(B), rng.integers(0, C, B)] = 1
+    cls = np.zeros((B, P), np.int64)
+    cls[np.arange(B), rng.integers(0, P, B)] = 1
+    eps = rng.standard_normal((B, L))
+    full = dict(x=x, batch=condm, sizefactor=x.sum(1), goodloc=np.ones((B, G), bool), classes=cls)
+    ref = orc.forward_backward(params, cfg, full, eps, gscale=(1, 1e-3, 1, 1))
+    lo, hi = comm.shard(B)
+    mine = {k: v[lo:hi] for k, v in full.items()}
+    loc = orc.forward_backward(params, cfg, mine, eps[lo:hi], gscale=(1, 1e-3, 1, 1))
+    # local recon / KL are means over the LOCAL rows: rescale to the global batch as the kernels do (inv_B)
+    share = (hi - lo) / B
+    scale = {"recon": share, "kl": share}
+    losses = torch.tensor([loc["losses"][0] * share, loc["losses"][1] * share, loc["losses"][2], loc["losses"][3]])
+    comm.allreduce_scalars(losses)
+    assert np.allclose(losses.numpy(), ref["losses"], rtol=1e-10)
+    # gradients: the CE part is a sum (no rescale); recon/KL parts scale with `share`.  Check on theta (pure recon).
+    gth = torch.tensor(loc["grads"]["theta"] * share)
+    comm.allreduce_bucket_async(gth)
+    assert np.allclose(gth.numpy(), ref["grads"]["theta"], rtol=1e-9, atol=1e-12)
+    # MMD: the gradient of the global MMD w.r.t. a rank's rows is the slice of the global gradient
+    z = rng.standard_normal((B, L))
+    m_all, d_all = orc.mmd_loss(z, condm, C, 2.0, None, None)
+    out[rank] = float(np.abs(d_all[lo:hi]).sum())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_host_logic_gloo_ws2():
+    port = 29500 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert len(out) == 2
+
+
+def test_loader_shards_global_batches():
+    from celligner2_amd.trainer import _Loader
+
+    class FakeDS:
+        device = torch.device("cpu")
+
+        def __len__(self):
+            return 23
+
+        def gather(self, idx, *a):
+            return idx
+
+    class W:
+        def __init__(self, r):
+            self.rank, self.world_size = r, 2
+
+    torch.manual_seed(3)
+    a = [b.tolist() for b in _Loader(FakeDS(), 8, None, None, "reference", world=W(0))]
+    torch.manual_seed(3)
+    b = [b.tolist() for b in _Loader(FakeDS(), 8, None, None, "reference", world=W(1))]
+    torch.manual_seed(3)
+    full = [c.tolist() for c in _Loader(FakeDS(), 8, None, None, "reference")]
+    assert len(a) == len(b) == len(full) == 3
+    for fa, fb, ff in zip(a, b, full):
+        per = len(ff) // 2
+        assert fa == ff[:per] and fb == ff[per:2 * per]
