@@ -1,0 +1,39 @@
+"""Micro-benchmark of the gene-width GEMMs at the C4 shapes (GPU box only)."""
+import sys, os, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from celligner2_amd import ops
+
+def bench(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3  # us
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    which = sys.argv[2] if len(sys.argv) > 2 else "all"
+    B, G, H = 4096, 19000, 1024
+    dev = "cuda"
+    dt = torch.bfloat16
+    x = torch.randn(B, G, device=dev).to(dt); w0 = torch.randn(H, G, device=dev).to(dt)
+    d1 = torch.randn(B, H, device=dev).to(dt); wout = torch.randn(G, H, device=dev).to(dt)
+    dl = torch.randn(B, G, device=dev).to(dt); dh0 = torch.randn(B, H, device=dev).to(dt)
+    flops = 2.0 * B * G * H
+    cases = {
+        "enc0_fwd  NT M=4096 N=1024 K=19000 ns=2": lambda y=torch.empty(2, B, H, device=dev): ops.linear_fwd(x, w0, y, nslab=2),
+        "head_fwd  NT M=4096 N=19000 K=1024": lambda y=torch.empty(B, G, device=dev): ops.linear_fwd(d1, wout, y),
+        "head_dgrad NN M=4096 N(out)=1024 R=19000 ns=2": lambda y=torch.empty(2, B, H, device=dev): ops.linear_dgrad(dl, wout, y, nslab=2),
+        "head_wgrad TN [19000,1024] R=4096": lambda y=torch.empty(G, H, device=dev): ops.linear_wgrad(dl, d1, y),
+        "enc0_wgrad TN [1024,19000] R=4096": lambda y=torch.empty(H, G, device=dev): ops.linear_wgrad(dh0, x, y),
+    }
+    for name, fn in cases.items():
+        if which != "all" and which not in name: continue
+        us = bench(fn, reps)
+        print(f"{name:50s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s")
+
+if __name__ == "__main__":
+    main()
