@@ -10,19 +10,11 @@
 // 128x128 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32, fp32 accumulate.
 // Register-staged pipeline: the global loads of K-tile t+1 are in flight while tile t is multiplied.
 // Split reductions write fp32 slabs (deterministic; the consumer kernel sums them).
-#include "common.h"
+#include <stdlib.h>
+
+#include "gemm.h"
 
 namespace c2 {
-
-struct GemmArgs {
-    const void* A;
-    const void* B;
-    float* C;
-    const float* bias;
-    const float* alpha_dev;
-    int64_t lda, ldb, ldc, slab_stride;
-    int M, N, R, r_per_split;
-};
 
 struct x3_t {};  // tag: fp32 operands in memory, multiplied as three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
 
@@ -315,11 +307,21 @@ static int gemm_layout(int layout, const GemmArgs& a, int nslab, hipStream_t str
     return launch_gemm<T, false, false>(a, nslab, stream);
 }
 
+// C2_GEMM_WIDE=0 keeps every GEMM on the 128x128 kernel (A/B runs of the two kernels).
+static bool wide_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("C2_GEMM_WIDE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream_t stream) {
     const int BK = dtype == C2_BF16 ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
     int64_t per = (a.R + nslab - 1) / nslab;
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
+    if (wide_enabled() && wide_eligible(layout, dtype, a)) return launch_gemm_wide(layout, a, nslab, stream);
     if (dtype == C2_BF16) return gemm_layout<bf16_t>(layout, a, nslab, stream);
     if (dtype == C2_F32X3) return gemm_layout<x3_t>(layout, a, nslab, stream);
     return gemm_layout<float>(layout, a, nslab, stream);
@@ -341,6 +343,14 @@ using namespace c2;
 static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) {
     return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
            M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
+}
+
+extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
+    GemmArgs a{};
+    a.M = (int)std::min<int64_t>(M, 1 << 30);
+    a.N = (int)std::min<int64_t>(N, 1 << 30);
+    a.R = (int)std::min<int64_t>(R, 1 << 30);
+    return (wide_enabled() && wide_eligible(0, dtype, a)) ? 256 : 128;
 }
 
 extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,

@@ -44,6 +44,11 @@ def _row_major(t, name):
     return t.stride(0)
 
 
+def gemm_tile(dtype, M, N, R, x3=False):
+    """Block-tile edge the library uses for an [M,N] output reduced over R with operands of `dtype`."""
+    return int(lib.c2_gemm_tile(_gemm_code(dtype, x3), M, N, R))
+
+
 def pick_nslab(tiles, R, bk=64, target=512, max_slab=16):
     """Split a long reduction so that the launch has >= ~2 blocks per CU."""
     if tiles >= target or R <= 4 * bk:

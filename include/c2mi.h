@@ -64,6 +64,11 @@ int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, in
                     int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
                     const float* alpha_dev, void* stream);
 
+/* Block-tile edge (128 or 256) the three GEMM entry points above use for operand dtype `dtype` and an
+ * [M,N] output reduced over R: callers size `nslab` from it so that a launch fills the 256 CUs.
+ * (No counterpart in the reference: torch picks its own BLAS blocking.) */
+int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R);
+
 /* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
 int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);
 

@@ -62,6 +62,45 @@ def test_linear_three_layouts(dtype, tol, M, N, K):
     assert rel(out, dy64.T @ a64) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1496, 1800, 1416), (2048, 1024, 2048), (1000, 2304, 4096 + 64 + 8), (4096, 19000, 520)])
+def test_linear_wide_bf16(M, N, K):
+    """Shapes that take the 256x256 LDS-DMA kernel (gemm_wide.hip): ragged tile edges, reduction tails that are
+    not a multiple of 64, split reductions.  The oracle sees the bf16-rounded operands, so only the fp32
+    accumulation order differs: 2e-5."""
+    ops = _ops()
+    assert ops.gemm_tile(torch.bfloat16, M, N, K) == 256
+    tol = 2e-5
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    ta = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    tw = torch.randn(N, K, generator=g).to(DEV).bfloat16()
+    tdy = torch.randn(M, N, generator=g).to(DEV).bfloat16()
+    bias = torch.randn(N, generator=g).to(DEV)
+    a64, w64, dy64 = ta.double(), tw.double(), tdy.double()
+    relt = lambda got, want: float((got.double() - want).abs().max() / want.abs().max())  # noqa: E731
+    y = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_fwd(ta, tw, y, bias=bias)
+    assert relt(y, a64 @ w64.T + bias.double()) < tol
+    for ns in (2, 5):
+        ys = torch.full((ns, M, N), float("nan"), device=DEV)
+        ops.linear_fwd(ta, tw, ys, nslab=ns)
+        assert relt(ys.sum(0), a64 @ w64.T) < tol
+    alpha = torch.tensor([0.5], device=DEV)
+    if ops.gemm_tile(torch.bfloat16, M, K, N) == 256:
+        da = torch.full((M, K), float("nan"), device=DEV)
+        ops.linear_dgrad(tdy, tw, da, alpha=alpha)
+        assert relt(da, 0.5 * dy64 @ w64) < tol
+        das = torch.full((3, M, K), float("nan"), device=DEV)
+        ops.linear_dgrad(tdy, tw, das, nslab=3)
+        assert relt(das.sum(0), dy64 @ w64) < tol
+    if ops.gemm_tile(torch.bfloat16, N, K, M) == 256:
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        ops.linear_wgrad(tdy, ta, dw, alpha=alpha)
+        assert relt(dw, 0.5 * dy64.T @ a64) < tol
+        dws = torch.full((2, N, K), float("nan"), device=DEV)
+        ops.linear_wgrad(tdy, ta, dws, nslab=2)
+        assert relt(dws.sum(0), dy64.T @ a64) < tol
+
+
 def test_linear_unaligned_views():
     """Operands with odd leading dimensions / offsets take the scalar-load path."""
     ops = _ops()

@@ -17,6 +17,7 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     which = sys.argv[2] if len(sys.argv) > 2 else "all"
     B, G, H = 4096, 19000, 1024
+    ns = int(os.environ.get("NS", "2"))
     dev = "cuda"
     dt = torch.bfloat16
     x = torch.randn(B, G, device=dev).to(dt); w0 = torch.randn(H, G, device=dev).to(dt)
@@ -24,9 +25,9 @@ def main():
     dl = torch.randn(B, G, device=dev).to(dt); dh0 = torch.randn(B, H, device=dev).to(dt)
     flops = 2.0 * B * G * H
     cases = {
-        "enc0_fwd  NT M=4096 N=1024 K=19000 ns=2": lambda y=torch.empty(2, B, H, device=dev): ops.linear_fwd(x, w0, y, nslab=2),
+        f"enc0_fwd  NT M=4096 N=1024 K=19000 ns={ns}": lambda y=torch.empty(ns, B, H, device=dev): ops.linear_fwd(x, w0, y, nslab=ns),
         "head_fwd  NT M=4096 N=19000 K=1024": lambda y=torch.empty(B, G, device=dev): ops.linear_fwd(d1, wout, y),
-        "head_dgrad NN M=4096 N(out)=1024 R=19000 ns=2": lambda y=torch.empty(2, B, H, device=dev): ops.linear_dgrad(dl, wout, y, nslab=2),
+        f"head_dgrad NN M=4096 N(out)=1024 R=19000 ns={ns}": lambda y=torch.empty(ns, B, H, device=dev): ops.linear_dgrad(dl, wout, y, nslab=ns),
         "head_wgrad TN [19000,1024] R=4096": lambda y=torch.empty(G, H, device=dev): ops.linear_wgrad(dl, d1, y),
         "enc0_wgrad TN [1024,19000] R=4096": lambda y=torch.empty(H, G, device=dev): ops.linear_wgrad(dh0, x, y),
     }
