@@ -178,8 +178,7 @@ class StepEngine:
     def _linear_slabs(self, key, a, wname, B):
         w = self.weight(wname)
         N, K = w.shape
-        tiles = ((B + 127) // 128) * ((N + 127) // 128)
-        ns = ops.pick_nslab(tiles, K)
+        ns = ops.pick_nslab(B, N, K, a.dtype, self.x3)
         y = self.buf(key + ".Y", (ns, B, N))
         ops.linear_fwd(a, w, y, nslab=ns, x3=self.x3)
         return y
@@ -189,8 +188,7 @@ class StepEngine:
         that the launch fills the chip, then sums them (deterministic)."""
         g = self.gbuf(name)
         N, K = g.shape
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        ns = ops.pick_nslab(tiles, dy.shape[0], bk=64 if dy.dtype != F32 else 32)
+        ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
         if ns == 1:
             ops.linear_wgrad(dy, a, g, alpha=alpha, x3=self.x3)
         else:
@@ -235,8 +233,7 @@ class StepEngine:
         w = self.weight(blk.w)
         K = w.shape[1]
         if out_slabs is None:
-            tiles = ((B + 127) // 128) * ((K + 127) // 128)
-            ns = ops.pick_nslab(tiles, H)
+            ns = ops.pick_nslab(B, K, H, dh.dtype, self.x3)
             out_slabs = self.buf(blk.name + ".da", (ns, B, K))
         ops.linear_dgrad(dh, w, out_slabs, nslab=out_slabs.shape[0], x3=self.x3)
         return out_slabs
@@ -370,8 +367,7 @@ class StepEngine:
             ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
         w = self.weight(hw)
         H1 = w.shape[1]
-        tiles = ((B + 127) // 128) * ((H1 + 127) // 128)
-        ns = ops.pick_nslab(tiles, G)
+        ns = ops.pick_nslab(B, H1, G, dlogits.dtype, self.x3)
         dd = self.buf("dhead.da", (ns, B, H1))
         ops.linear_dgrad(dlogits, w, dd, nslab=ns, alpha=gr, x3=self.x3)
         if cfg["recon_loss"] == "nb" and rq("theta"):

@@ -49,8 +49,13 @@ def gemm_tile(dtype, M, N, R, x3=False):
     return int(lib.c2_gemm_tile(_gemm_code(dtype, x3), M, N, R))
 
 
-def pick_nslab(tiles, R, bk=64, target=512, max_slab=16):
-    """Split a long reduction so that the launch has >= ~2 blocks per CU."""
+def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16):
+    """Number of slabs a reduction of length R is split into for an [M,N] output, so that the launch fills the
+    256 CUs: >= ~2 blocks per CU of the 128x128 kernel, one 512-thread block per CU of the 256x256 kernel."""
+    tile = gemm_tile(dtype, M, N, R, x3)
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
+    bk = 64 if dtype != torch.float32 else 32
+    target = 256 if tile == 256 else 512
     if tiles >= target or R <= 4 * bk:
         return 1
     n = min(max_slab, (target + tiles - 1) // tiles, max(1, R // (4 * bk)))
