@@ -217,40 +217,89 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// db / dWc: stage 1 -- block = 256 columns x RB rows; stage 2 -- sum over row chunks.
-constexpr int kBCG_RB = 64;
+// db / dWc: stage 1 -- block = 128 columns x RB rows: thread (cx, ry) sums 2 adjacent columns over every 8th row of
+// the chunk in ONE pass (bias and up to 8 condition columns together), the 8 row groups are combined through LDS;
+// stage 2 -- sum over row chunks (independent loads, unrolled).
+constexpr int kBCG_RB = 128;
+constexpr int kBCG_MAXC = 8;
 template <typename TI>
-__global__ __launch_bounds__(256) void bias_cond_stage1(const TI* __restrict__ dh, int64_t lddh,
-                                                        const int64_t* __restrict__ cond, int C, int64_t B, int H,
+__device__ __forceinline__ void ld2(const TI* p, bool two, float& v0, float& v1);
+template <>
+__device__ __forceinline__ void ld2<float>(const float* p, bool two, float& v0, float& v1) {
+    v0 = p[0];
+    v1 = two ? p[1] : 0.f;
+}
+template <>
+__device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, bool two, float& v0, float& v1) {
+    v0 = bf2f(p[0]);
+    v1 = two ? bf2f(p[1]) : 0.f;
+}
+template <typename TI, int CC>
+__global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ dh, int64_t lddh,
+                                                        const int64_t* __restrict__ cond, int C, int c0, int64_t B, int H,
                                                         float* __restrict__ ws /*[nchunk][1+C][H]*/) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][(1 + CC)][128];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 128 + 2 * cx;
     const int chunk = blockIdx.y;
     const int64_t b0 = (int64_t)chunk * kBCG_RB, b1 = min(B, b0 + kBCG_RB);
-    float* out = ws + (int64_t)chunk * (1 + C) * H;
-    if (col >= H) return;
-    float a0 = 0.f;
-    for (int64_t b = b0; b < b1; ++b) a0 += ld_as_f32<TI>(dh + b * lddh + col);
-    out[col] = a0;
-    for (int j0 = 0; j0 < C; j0 += 8) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int64_t b = b0; b < b1; ++b) {
-            const float v = ld_as_f32<TI>(dh + b * lddh + col);
+    float a0[2] = {0.f, 0.f};
+    float acc[CC > 0 ? CC : 1][2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j0 + j < C) acc[j] += v * (float)cond[b * C + j0 + j];
+    for (int j = 0; j < CC; ++j) acc[j][0] = acc[j][1] = 0.f;
+    if (col < H) {
+        const bool two = col + 1 < H;
+        for (int64_t b = b0 + ry; b < b1; b += 8) {
+            float v0, v1;
+            ld2<TI>(dh + b * lddh + col, two, v0, v1);
+            a0[0] += v0;
+            a0[1] += v1;
+#pragma unroll
+            for (int j = 0; j < CC; ++j) {
+                const float cj = (c0 + j < C) ? (float)cond[b * C + c0 + j] : 0.f;
+                acc[j][0] += v0 * cj;
+                acc[j][1] += v1 * cj;
+            }
         }
+    }
+    red[ry][0][2 * cx] = a0[0];
+    red[ry][0][2 * cx + 1] = a0[1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j0 + j < C) out[(int64_t)(1 + j0 + j) * H + col] = acc[j];
+    for (int j = 0; j < CC; ++j) {
+        red[ry][1 + j][2 * cx] = acc[j][0];
+        red[ry][1 + j][2 * cx + 1] = acc[j][1];
+    }
+    __syncthreads();
+    float* out = ws + (int64_t)chunk * (1 + C) * H;
+    for (int i = threadIdx.x; i < (1 + CC) * 128; i += 512) {
+        const int k = i >> 7, c = i & 127;
+        const int gc = blockIdx.x * 128 + c;
+        if (gc >= H) continue;
+        if (k == 0 && c0 != 0) continue;          // the bias row is written by the first condition group only
+        if (k > 0 && c0 + k - 1 >= C) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][k][c];
+        out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = s;
     }
 }
-__global__ void bias_cond_stage2(const float* __restrict__ ws, int nchunk, int C, int H, float* __restrict__ db,
-                                 float* __restrict__ dWc, int64_t lddwc, const float* __restrict__ alpha_dev) {
+__global__ __launch_bounds__(256) void bias_cond_stage2(const float* __restrict__ ws, int nchunk, int C, int H,
+                                                        float* __restrict__ db, float* __restrict__ dWc, int64_t lddwc,
+                                                        const float* __restrict__ alpha_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (1+C)*H
     if (i >= (1 + C) * H) return;
     const int k = i / H, col = i - k * H;
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += ws[(int64_t)c * (1 + C) * H + i];
+    const int64_t stride = (int64_t)(1 + C) * H;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= nchunk; c += 4) {
+        s0 += ws[(c + 0) * stride + i];
+        s1 += ws[(c + 1) * stride + i];
+        s2 += ws[(c + 2) * stride + i];
+        s3 += ws[(c + 3) * stride + i];
+    }
+    for (; c < nchunk; ++c) s0 += ws[c * stride + i];
+    float s = (s0 + s1) + (s2 + s3);
     const float alpha = alpha_dev ? *alpha_dev : 1.f;
     s *= alpha;
     if (k == 0) {
@@ -517,11 +566,22 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
     if (!dWc) C = 0;
     const int nchunk = (int)std::max<int64_t>(1, (B + kBCG_RB - 1) / kBCG_RB);
     hipStream_t st = (hipStream_t)stream;
-    dim3 g1((unsigned)((H + 255) / 256), nchunk);
-    if (dh_dtype == C2_F32)
-        hipLaunchKernelGGL((bias_cond_stage1<float>), g1, dim3(256), 0, st, (const float*)dh, lddh, cond, C, B, (int)H, ws);
-    else
-        hipLaunchKernelGGL((bias_cond_stage1<bf16_t>), g1, dim3(256), 0, st, (const bf16_t*)dh, lddh, cond, C, B, (int)H, ws);
+    dim3 g1((unsigned)((H + 127) / 128), nchunk);
+#define BCG_L(TI, CC, c0) \
+    hipLaunchKernelGGL((bias_cond_stage1<TI, CC>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, ws)
+    for (int c0 = 0; c0 == 0 || c0 < C; c0 += kBCG_MAXC) {
+        const int left = C - c0;
+        if (dh_dtype == C2_F32) {
+            if (left <= 0) BCG_L(float, 0, c0);
+            else if (left <= 4) BCG_L(float, 4, c0);
+            else BCG_L(float, 8, c0);
+        } else {
+            if (left <= 0) BCG_L(bf16_t, 0, c0);
+            else if (left <= 4) BCG_L(bf16_t, 4, c0);
+            else BCG_L(bf16_t, 8, c0);
+        }
+    }
+#undef BCG_L
     const int n2 = (int)((1 + C) * H);
     hipLaunchKernelGGL(bias_cond_stage2, dim3((n2 + 255) / 256), dim3(256), 0, st, ws, nchunk, C, (int)H, db, dWc,
                        lddwc, alpha_dev);

@@ -84,6 +84,7 @@ struct NbArgs {
     int* part_flag;    // [ngroups][3]
     float* part_loss;  // [ngroups]
     int32_t* status;
+    const float* lgx;  // optional [B]: sum_g goodloc * lgamma(x+1) of each row (a constant of the data), or NULL
     int64_t ldl, ldx, ldg, lddl, B, G;
     int C;
     float inv_B;
@@ -125,6 +126,29 @@ __device__ __forceinline__ float digamma_fast(float z) {
     const float r2 = r * r;
     const float series = r2 * (0.083333333333f - r2 * (0.008333333333f - r2 * (0.003968253968f - r2 * 0.004166666667f)));
     return flog(zs) - 0.5f * r - series - corr;
+}
+
+// lgamma(z) and digamma(z), z > 0, with ONE shared upward shift (by 6 when z < 6): four transcendentals
+// (rcp, log of the shifted argument; log, rcp of the shift product) instead of six, no divergent branch.
+// Truncation of both asymptotic series at z >= 6 is below 2e-10.
+__device__ __forceinline__ void lgam_digam_fast(float z, float& lg, float& dg) {
+    const bool small = z < 6.0f;
+    float P = z, dP = 1.f;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        const float t = z + (float)k;
+        dP = dP * t + P;
+        P = P * t;
+    }
+    const float zs = small ? z + 6.0f : z;
+    P = small ? P : 1.0f;
+    dP = small ? dP : 0.0f;
+    const float r = frcp(zs), lz = flog(zs);
+    const float r2 = r * r;
+    lg = (zs - 0.5f) * lz - zs + 0.918938533205f +
+         r * (0.083333333333f + r2 * (-0.002777777778f + r2 * (0.000793650794f - r2 * 0.000595238095f))) - flog(P);
+    dg = lz - 0.5f * r - r2 * (0.083333333333f - r2 * (0.008333333333f - r2 * (0.003968253968f - r2 * 0.004166666667f))) -
+         dP * frcp(P);
 }
 
 // One workgroup walks whole rows.  Nothing of a row is kept in registers between its passes: the row (76 KB at
@@ -264,7 +288,8 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
                          const float ltm = flog(tm);
                          const float zt = x + th;
                          // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
-                         const float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lgamma_fast(zt) - lgamma_fast(x + 1.0f);
+                         const float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lgamma_fast(zt) -
+                                          (a.lgx ? 0.f : lgamma_fast(x + 1.0f));
                          const float rtm = frcp(tm);
                          const float dmu_mu = x * mu * frcp(mu + eps) - zt * mu * rtm;  // mu * dll/dmu
                          // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
@@ -296,6 +321,7 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
                              }
                      }
                  });
+        if (a.lgx && tid == 0) loss_acc -= a.lgx[row];
     }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
 // Fast path (16-byte aligned rows, G % 4 == 0): the row's logits, counts and mask live in registers, every load of
 // a pass is in flight at once, and while chunk i of pass 4 is being evaluated the NEXT row's chunk i is already
 // being fetched into the registers chunk i has just released -- HBM latency hides under the log-likelihood maths.
-template <typename TD, int NT, int NV>
+template <typename TD, int NT, int NV, bool HAS_LGX>
 __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dacc[];
     __shared__ float red[32];
@@ -330,7 +356,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         flushed |= 1 << pat;
         __syncthreads();
     };
-    f32x4 ev[NV], xv[NV];
+    f32x4 ev[NV], xv[NV], pg[NV];
     unsigned mb[NV];
     const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -396,7 +422,8 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                 const float mu = sf * ev[i][k] * inv_sum;
                 const float zt = xv[i][k] + t0[k];
                 const float v = xv[i][k] * mu * frcp(mu + eps) - zt * mu * frcp(t0[k] + mu + eps);
-                S += ((mb[i] >> (8 * k)) & 0xffu) ? scale * v : 0.f;
+                pg[i][k] = ((mb[i] >> (8 * k)) & 0xffu) ? scale * v : 0.f;  // p * dloss/dp, kept for pass 4
+                S += pg[i][k];
             }
         }
         S = block_sum<NT>(S, red);
@@ -420,12 +447,12 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                     const float tm = th + mu + eps;
                     const float ltm = flog(tm);
                     const float zt = x + th;
-                    const float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lgamma_fast(zt) - lgamma_fast(x + 1.0f);
-                    const float rtm = frcp(tm);
-                    const float dmu_mu = x * mu * frcp(mu + eps) - zt * mu * rtm;
-                    const float dth = t2[k] - ltm - zt * rtm + digamma_fast(zt);
-                    const float pg = m ? scale * dmu_mu : 0.f;
-                    d[k] = pg - p * S;
+                    float lg, dg;
+                    lgam_digam_fast(zt, lg, dg);
+                    float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lg;
+                    if (!HAS_LGX) ll -= lgamma_fast(x + 1.0f);
+                    const float dth = t2[k] - ltm - zt * frcp(tm) + dg;
+                    d[k] = pg[i][k] - p * S;
                     dt[k] = m ? scale * th * dth : 0.f;
                     loss_acc += m ? ll : 0.f;
                 }
@@ -444,6 +471,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             }
             if (nrow < a.B) fetch(i, nrow);  // registers of chunk i are free: start the next row's loads
         }
+        if (HAS_LGX && tid == 0) loss_acc -= a.lgx[row];
         pref_row = nrow < a.B ? nrow : -1;
     }
     if (cur_pat >= 0) flush(cur_pat);
@@ -487,6 +515,19 @@ __global__ __launch_bounds__(256) void nb_dtheta_stage2(const float* __restrict_
         if (j == 1) v = s[1] + s[2];
         dtheta[g * C + j] = v;
     }
+}
+
+// Row constant of the NB log-likelihood: out[b] = sum_g goodloc * lgamma(x + 1) -- a function of the data only.
+__global__ __launch_bounds__(256) void nb_row_const_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const uint8_t* __restrict__ goodloc, int64_t ldg, int64_t G,
+                                                           float* __restrict__ out) {
+    __shared__ float red[32];
+    const int64_t row = blockIdx.x;
+    float acc = 0.f;
+    for (int64_t c = threadIdx.x; c < G; c += 256)
+        if (goodloc[row * ldg + c]) acc += lgamma_pos(x[row * ldx + c] + 1.0f);
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) out[row] = acc;
 }
 
 constexpr int kNbMaxGroups = 512;
@@ -591,9 +632,14 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     } while (0)
 #define NB_F(NT, NV)                                                                                          \
     do {                                                                                                      \
-        auto kf = nb_rowreg_kernel<TD, NT, NV>;                                                                \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), lds, st, a);                                           \
+        auto kf = nb_rowreg_kernel<TD, NT, NV, false>;                                                         \
+        auto kl = nb_rowreg_kernel<TD, NT, NV, true>;                                                          \
+        if (lds > 48 * 1024) {                                                                                \
+            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        }                                                                                                     \
+        if (a.lgx) hipLaunchKernelGGL(kl, dim3(ngroups), dim3(NT), lds, st, a);                                \
+        else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), lds, st, a);                                      \
         return 0;                                                                                             \
     } while (0)
     if (vec) {
@@ -618,7 +664,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                                    const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
                                    const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
                                    void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
-                                   int32_t* status_dev, void* stream) {
+                                   int32_t* status_dev, const float* lgx1_rowsum, void* stream) {
     C2_CHECK(logits && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dtheta && ws && status_dev,
              "null pointer");
     C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
@@ -634,7 +680,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             ldl, ldx, ldg, lddl, B, G, C, inv_B};
+             lgx1_rowsum, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
@@ -645,6 +691,17 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                        ngroups, G, part2);
     hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_nb_row_const(const float* x, int64_t ldx, const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G,
+                               float* out, void* stream) {
+    C2_CHECK(x && goodloc && out, "null pointer");
+    C2_CHECK(ldx >= G && ldg >= G && B < (1ll << 31), "bad shape");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(nb_row_const_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ldx, goodloc, ldg, G,
+                       out);
     C2_LAUNCH_CHECK();
     return 0;
 }

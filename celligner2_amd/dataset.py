@@ -122,7 +122,16 @@ class DeviceDataset:
                 strat += np.where(mat[i], w[i], 0)
         return strat + self.minweight
 
-    def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None):
+    @property
+    def nb_row_const(self):
+        """[n] fp32: sum_g goodloc*lgamma(x+1) per row, the data-only term of the NB likelihood (losses.py:60-64),
+        evaluated once for the resident matrix (like the size factors, trainers/celligner2/_utils.py:149-152)."""
+        c = getattr(self, "_nb_row_const", None)
+        if c is None:
+            c = self._nb_row_const = ops.nb_row_const(self.data, self.goodloc)
+        return c
+
+    def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None, nb_const=False):
         """Batch dict for rows `idx` (int64 device tensor): the keys custom_collate would produce
         (trainers/celligner2/_utils.py:188-225) plus `xin`, the encoder input written by the same kernel."""
         n = idx.numel()
@@ -148,6 +157,8 @@ class DeviceDataset:
         ops.gather_rows(self.data, self.goodloc, self.size_factors, self.conditions if cond_o is not None else None,
                         self.predictors if cls_o is not None else None, idx, out["x"], out["goodloc"],
                         out["sizefactor"], cond_o, cls_o, xin, apply_log)
+        if nb_const:
+            out["lgx1"] = torch.index_select(self.nb_row_const, 0, idx, out=get("lgx1", (n,), torch.float32))
         return out
 
 

@@ -301,7 +301,8 @@ class StepEngine:
             C = cfg["n_conditions"]
             ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
             ops.recon_nb(logits, x, batch["goodloc"], batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
-                         losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1])
+                         losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
+                         lgx1=batch.get("lgx1"))
         elif cfg["recon_loss"] == "mse":
             ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws)
         else:

@@ -337,7 +337,7 @@ class Celligner2(nn.Module):
 
     # ------------------------------------------------------------------ the reference's API
     def forward(self, x=None, batch=None, sizefactor=None, classes=None, weight=None, goodloc=None,
-                main_dataset=None, xin=None):
+                main_dataset=None, xin=None, lgx1=None):
         dev = x.device
         B = x.shape[0]
         x = x.float().contiguous()
@@ -357,6 +357,8 @@ class Celligner2(nn.Module):
             bt["classes"] = classes
         if xin is not None:
             bt["xin"] = xin
+        if lgx1 is not None:  # per-row sum of goodloc*lgamma(x+1), precomputed by a resident dataset
+            bt["lgx1"] = lgx1.float().contiguous()
         eps, masks = self._draw_noise(B, classes is not None, dev)
         params = [p for _, p in self.named_parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):

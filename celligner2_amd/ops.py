@@ -200,17 +200,31 @@ def recon_nb_ws(B, G, C):
     return int(lib.c2_recon_nb_ws(B, G, C))
 
 
-def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status):
+def nb_row_const(x, goodloc, out=None):
+    """out[b] = sum_g goodloc * lgamma(x+1) (data-only term of the NB likelihood)."""
+    L.require_gpu(x, goodloc)
+    B, G = x.shape
+    assert goodloc.dtype in (torch.bool, torch.uint8) and tuple(goodloc.shape) == (B, G) and x.dtype == torch.float32
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib.c2_nb_row_const(ptr(x), _row_major(x, "x"), ptr(goodloc), _row_major(goodloc, "goodloc"), B, G, ptr(out),
+                              stream()))
+    return out
+
+
+def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status, lgx1=None):
     L.require_gpu(logits, x, goodloc, dlogits)
     B, G = x.shape
     C = theta.shape[1]
     assert goodloc.dtype in (torch.bool, torch.uint8) and theta.is_contiguous() and cond.is_contiguous()
     assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
     assert ws.numel() >= recon_nb_ws(B, G, C) and sizefactor.dtype == torch.float32 and sizefactor.is_contiguous()
+    if lgx1 is not None:
+        assert lgx1.dtype == torch.float32 and lgx1.is_contiguous() and lgx1.numel() == B and lgx1.is_cuda
     check(lib.c2_recon_nb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"), ptr(goodloc),
                                   _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta), ptr(cond), C, B, G,
                                   float(inv_B), ptr(loss_out), ptr(dlogits), dt_code(dlogits.dtype),
-                                  _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws), ptr(status), stream()))
+                                  _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws), ptr(status), ptr(lgx1), stream()))
 
 
 def recon_mse(logits, x, goodloc, inv_B, loss_out, dlogits, ws):

@@ -111,7 +111,8 @@ class _Loader:
     rng="device" draws on the GPU generator."""
 
     def __init__(self, dataset, batch_size, weights=None, num_samples=None, rng="reference", xin_dtype=None,
-                 apply_log=False, world=None):
+                 apply_log=False, world=None, nb_const=False):
+        self.nb_const = nb_const  # deliver the data-only NB term (sum goodloc*lgamma(x+1)) with every batch
         self.ds, self.bs, self.weights, self.num_samples, self.rng = dataset, batch_size, weights, num_samples, rng
         self.xin_dtype, self.apply_log = xin_dtype, apply_log
         self.world = world  # data-parallel: batch_size is the GLOBAL batch, each rank gathers its own slice
@@ -149,7 +150,8 @@ class _Loader:
                 if per == 0:
                     continue
                 sub = sub[self.world.rank * per:(self.world.rank + 1) * per]
-            yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}))
+            yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}),
+                                 self.nb_const)
 
 
 class Trainer:
@@ -234,17 +236,19 @@ class Trainer:
         log_in = self.model.applylog and self.model.recon_loss != "mse"
         if not log_in and xin_dtype == torch.float32:
             xin_dtype = None  # the encoder reads x itself
+        nbc = self.model.recon_loss == "nb"
         if self.use_stratified_sampling:
             weights = torch.tensor(self.train_data.stratifier_weights)
             self.dataloader_train = _Loader(self.train_data, self.batch_size, weights, self.n_samples, self.rng,
-                                            xin_dtype, log_in, self.world)
+                                            xin_dtype, log_in, self.world, nbc)
         else:
             self.dataloader_train = _Loader(self.train_data, self.batch_size, None, None, self.rng, xin_dtype, log_in,
-                                            self.world)
+                                            self.world, nbc)
         if self.valid_data is not None:
             val_bs = min(self.batch_size, len(self.valid_data))
             self.val_iters_per_epoch = int(np.ceil(len(self.valid_data) / self.batch_size))
-            self.dataloader_valid = _Loader(self.valid_data, val_bs, None, None, self.rng, xin_dtype, log_in, self.world)
+            self.dataloader_valid = _Loader(self.valid_data, val_bs, None, None, self.rng, xin_dtype, log_in, self.world,
+                                            nbc)
 
     def calc_alpha_coeff(self):
         """trainer.py:231-253."""

@@ -119,12 +119,20 @@ int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64_t slab_str
  *   p = softmax(logits); mu = sizefactor*p; theta_b = exp(q_b . theta^T) with q_b the scatter-quirk
  *   vector of the multi-hot row; ll as losses.py:57-65; recon = -(1/Bn) sum goodloc*ll.
  * Adds recon to *loss_out; writes dlogits (dtype dl_dtype, unit upstream gradient) and dtheta [G,C].
- * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set non-zero if a cond value is outside [0,C). */
+ * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set non-zero if a cond value is outside [0,C).
+ * lgx1_rowsum: NULL, or [B] with sum_g goodloc*lgamma(x+1) of each row (c2_nb_row_const): that term of
+ * losses.py:60-64 depends on the data only, so a resident dataset evaluates it once instead of every step. */
 size_t c2_recon_nb_ws(int64_t B, int64_t G, int C);
 int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
                         int64_t ldg, const float* sizefactor, const float* theta, const int64_t* cond, int C,
                         int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
-                        int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, void* stream);
+                        int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
+                        void* stream);
+
+/* out[b] = sum_g goodloc[b][g] * lgamma(x[b][g] + 1): the data-only term of the NB log-likelihood
+ * (losses.py:60-64, `- torch.lgamma(x + 1)`), for c2_recon_nb_fwd_bwd's lgx1_rowsum. */
+int c2_nb_row_const(const float* x, int64_t ldx, const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G,
+                    float* out, void* stream);
 
 /* MSE reconstruction (intent of celligner2.py:283-285; losses.py:9-24):  r = relu(logits);
  *   recon = (1/Bn) sum goodloc*(r-x)^2;  dlogits = (2/Bn)*goodloc*(r-x)*[logits>0]. */

@@ -164,6 +164,27 @@ def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
         assert rel(dwct, dh_np.T @ cond[:, :C]) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,C", [(1000, 515, 11), (300, 19000, 0), (129, 77, 5), (4096, 1024, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_cond_grad(B, H, C, dtype):
+    """Column sums over many row chunks, more condition columns than one pass holds (8), ragged edges."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(B + H + C)
+    dh = torch.randn(B, H, generator=g).to(DEV).to(dtype)
+    cond = (torch.rand(B, max(C, 1), generator=g) < 0.4).long().to(DEV)[:, :C].contiguous()
+    alpha = torch.tensor([0.7], device=DEV)
+    ws = torch.empty(ops.bias_cond_grad_ws(B, H, C), device=DEV)
+    db = torch.full((H,), float("nan"), device=DEV)
+    dwc = torch.full((H, C), float("nan"), device=DEV) if C else None
+    ops.bias_cond_grad(dh, cond if C else None, db, dwc, ws, alpha=alpha)
+    d64 = dh.double()
+    want_b = 0.7 * d64.sum(0)
+    assert float((db.double() - want_b).abs().max() / want_b.abs().max()) < 1e-5
+    if C:
+        want_c = 0.7 * d64.T @ cond.double()
+        assert float((dwc.double() - want_c).abs().max() / want_c.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("use_own_kl", [0, 1])
 def test_reparam_kl(use_own_kl):
     ops = _ops()
@@ -225,6 +246,18 @@ def test_recon_nb(B, G, C, multi, dl_dtype):
     assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
     assert rel(dl, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
     assert rel(dth, dth64) < 1e-4
+    # same call with the data-only term sum goodloc*lgamma(x+1) handed in (resident-dataset path)
+    from scipy.special import gammaln
+    lgx = ops.nb_row_const(T(x), T(good))
+    want = (gammaln(x.astype(np.float64) + 1.0) * good).sum(1)
+    assert rel(lgx, want) < 1e-5
+    loss2 = torch.zeros(1, device=DEV)
+    dl2 = torch.empty(B, G, device=DEV, dtype=dl_dtype)
+    dth2 = torch.empty(G, C, device=DEV)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss2, dl2, dth2, ws, status, lgx1=lgx)
+    assert abs(loss2.item() - recon64) < 1e-4 * abs(recon64)
+    assert rel(dl2, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
+    assert rel(dth2, dth64) < 1e-4
 
 
 def test_recon_nb_golden_wide_row():
