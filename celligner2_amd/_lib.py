@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libc2mi.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3, BF16X3P = 0, 1, 2, 3
 MMD_MAX_PARTS = 64
 
 if not os.path.exists(LIB_PATH):
@@ -36,6 +36,7 @@ _SIGS = {
     "c2_linear_dgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_gemm_tile": (i32, [i32, i64, i64, i64]),
+    "c2_split_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
     "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp]),
     "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp]),

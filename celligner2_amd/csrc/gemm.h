@@ -16,10 +16,12 @@ struct GemmArgs {
     const float* alpha_dev;
     int64_t lda, ldb, ldc, slab_stride;
     int M, N, R, r_per_split;
+    const void* A_lo;  // C2_BF16X3P: the low bf16 planes of the two operands (same layout / leading dimension)
+    const void* B_lo;
 };
 
-// Tile edge the library will use for a bf16 GEMM of this shape (256 when gemm_wide takes it, else 128).
-bool wide_eligible(int layout, int dtype, const GemmArgs& a);
-int launch_gemm_wide(int layout, const GemmArgs& a, int nslab, hipStream_t stream);
+// Block-tile edge gemm_wide.hip uses for this problem (256 or 128), or 0 when it does not take it.
+int wide_tile(int dtype, const GemmArgs& a);
+int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream);
 
 }  // namespace c2

@@ -317,11 +317,13 @@ static bool wide_enabled() {
 }
 
 static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream_t stream) {
-    const int BK = dtype == C2_BF16 ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
+    const int BK = (dtype == C2_BF16 || dtype == C2_BF16X3P) ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
     int64_t per = (a.R + nslab - 1) / nslab;
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
-    if (wide_enabled() && wide_eligible(layout, dtype, a)) return launch_gemm_wide(layout, a, nslab, stream);
+    const int wt = (wide_enabled() || dtype == C2_BF16X3P) ? wide_tile(dtype, a) : 0;
+    if (wt) return launch_gemm_wide(layout, wt, a, nslab, stream);
+    if (dtype == C2_BF16X3P) return 3;  // planes only run on the LDS-DMA kernels
     if (dtype == C2_BF16) return gemm_layout<bf16_t>(layout, a, nslab, stream);
     if (dtype == C2_F32X3) return gemm_layout<x3_t>(layout, a, nslab, stream);
     return gemm_layout<float>(layout, a, nslab, stream);
@@ -341,7 +343,7 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int
 using namespace c2;
 
 static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) {
-    return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
+    return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3 || dtype == C2_BF16X3P) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
            M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
 
@@ -350,7 +352,58 @@ extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
     a.M = (int)std::min<int64_t>(M, 1 << 30);
     a.N = (int)std::min<int64_t>(N, 1 << 30);
     a.R = (int)std::min<int64_t>(R, 1 << 30);
-    return (wide_enabled() && wide_eligible(0, dtype, a)) ? 256 : 128;
+    if (dtype == C2_BF16X3P) return wide_tile(dtype, a);
+    const int wt = wide_enabled() ? wide_tile(dtype, a) : 0;
+    return wt ? wt : 128;
+}
+
+__global__ void split_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
+                                  bf16_t* __restrict__ dst, int64_t ldd, bool vec) {
+    const int64_t plane = rows * ldd;
+    if (vec) {
+        const int64_t c4 = cols >> 2, n = rows * c4;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / c4, c = (i - r * c4) << 2;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld + c);
+            bf16_t h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = f2bf(v[e]);
+                l[e] = f2bf(v[e] - bf2f(h[e]));
+            }
+            u32x2 ph, pl;
+            ph[0] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+            ph[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+            pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+            pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+            *reinterpret_cast<u32x2*>(dst + r * ldd + c) = ph;
+            *reinterpret_cast<u32x2*>(dst + plane + r * ldd + c) = pl;
+        }
+    } else {
+        const int64_t n = rows * cols;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / cols, c = i - r * cols;
+            const float v = src[r * ld + c];
+            const bf16_t h = f2bf(v);
+            dst[r * ldd + c] = h;
+            dst[plane + r * ldd + c] = f2bf(v - bf2f(h));
+        }
+    }
+}
+
+extern "C" int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd,
+                             void* stream) {
+    C2_CHECK(src && dst, "null pointer");
+    C2_CHECK(rows >= 0 && cols >= 0 && ld >= cols && ldd >= cols, "bad shape");
+    if (rows == 0 || cols == 0) return 0;
+    const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && (ldd % 4 == 0) && aligned16(src) &&
+                     ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) && ((rows * ldd) % 4 == 0);
+    const int64_t n = vec ? rows * (cols / 4) : rows * cols;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, rows, cols, ld,
+                       (bf16_t*)dst, ldd, vec);
+    C2_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
@@ -362,8 +415,12 @@ extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t 
     C2_CHECK(!(bias && nslab != 1), "bias needs nslab == 1");
     C2_CHECK(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
     if (M == 0 || N == 0) return 0;
-    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0};
-    gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream);
+    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr};
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = (const bf16_t*)A + M * lda;
+        a.B_lo = (const bf16_t*)W + N * ldw;
+    }
+    C2_CHECK(gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -377,8 +434,12 @@ extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int6
     C2_CHECK(nslab == 1 || slab_stride >= M * ldda, "slab_stride too small");
     if (M == 0 || K == 0) return 0;
     // C[m][k] = sum_n dY[m][n] W[n][k]:  A-op = dY (RC over n), B-op = W ([n][k]: XC, output index k contiguous)
-    GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0};
-    gemm_dispatch(1, dtype, a, nslab, (hipStream_t)stream);
+    GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0, nullptr, nullptr};
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = (const bf16_t*)dY + M * lddy;
+        a.B_lo = (const bf16_t*)W + N * ldw;
+    }
+    C2_CHECK(gemm_dispatch(1, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -392,8 +453,12 @@ extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int6
     C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
     if (N == 0 || K == 0) return 0;
     // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
-    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0};
-    gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream);
+    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr};
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = (const bf16_t*)dY + M * lddy;
+        a.B_lo = (const bf16_t*)A + M * lda;
+    }
+    C2_CHECK(gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }

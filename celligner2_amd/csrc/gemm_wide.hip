@@ -1,7 +1,11 @@
-// Gene-width bf16 GEMMs (encoder L0 / decoder output layer: forward, dgrad, wgrad) for gfx950.
+// LDS-DMA bf16 GEMMs (forward, dgrad, wgrad of the Linear layers) for gfx950.
 //
-// 256x256 block tile, BK = 64, 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles of v_mfma_f32_32x32x16_bf16,
-// fp32 accumulate.  Operand tiles (32 KB each) are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no
+// Two instances of one template:
+//   NW = 8: 256x256 block tile, 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles -- the gene-width layers;
+//   NW = 4: 128x128 block tile, 4 waves (2 x 2), each wave  64x64 = 2x2 MFMA tiles, two blocks per CU -- the narrow
+//           hidden layers, whose fp32 operands arrive as two bf16 planes (hi, lo = x - hi) and are multiplied as
+//           three products hi*hi + hi*lo + lo*hi over a three-segment virtual reduction ("bf16x3").
+// BK = 64, v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Operand tiles (32 KB each) are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no
 // registers, no ds_write) into a RING OF FIVE 32 KB slots (all 160 KB of LDS): loads alternate A_t, B_t, A_t+1, ...
 // and load n lives in slot n % 5.  One raw s_barrier per K-tile; the wait in front of it is a COUNTED vmcnt that
 // leaves the newest load in flight, so the DMA stream never drains: while tile t is multiplied, B_t+1 and A_t+2
@@ -24,19 +28,16 @@
 namespace c2 {
 namespace wide {
 
-constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
-constexpr int TILE_BYTES = 256 * BK * 2;      // one operand tile = one ring slot: 32 KB
-constexpr int NSLOT = 5;
-constexpr int LDS_BYTES = NSLOT * TILE_BYTES; // 160 KB
-constexpr int GROUP_M = 8;                    // tiles along M that share a panel of B
+constexpr int BK = 64;
+constexpr int GROUP_M = 8;  // tiles along M that share a panel of B
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void g_void;
 
-// Per-lane source offsets (elements, relative to the tile's first row / column at reduction index 0) of the 4
-// LDS-DMA instructions a wave issues for one operand tile.  Instruction i = 4*wave + j writes LDS bytes
+// Per-lane source offset (elements, relative to the tile's first row / column at reduction index 0) of LDS-DMA
+// instruction i = 4*wave + j of one operand tile of BX rows (RC) / BX columns (XC).  Instruction i writes LDS bytes
 // [1024*i, 1024*i + 1024), lane l the 16 B at 1024*i + 16*l.
-template <bool RC>
+template <bool RC, int BX>
 __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot, int wave, int lane) {
     const int i = 4 * wave + j;
     if (RC) {
@@ -45,7 +46,8 @@ __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot,
         const int x = min(row, xtot - 1 - x0);  // rows past the edge re-read the last row (outputs discarded)
         return x * (int)ld + c * 8;
     } else {
-        const int k = 2 * i + (lane >> 5), p = lane & 31;
+        constexpr int LPR = BX / 8;  // lanes (16-byte chunks) per k-row
+        const int k = (64 / LPR) * i + lane / LPR, p = lane % LPR;
         const int ch = (((p >> 2) ^ (k & 3)) << 2) | (p & 3);
         int x = ch * 8;
         if (x0 + x >= xtot) x = 0;  // chunk entirely past the edge: any valid address (outputs discarded)
@@ -54,14 +56,15 @@ __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot,
 }
 
 // First reduction index (inside the K-tile) of the chunk that lane `lane` moves in instruction j.
-template <bool RC>
+template <bool RC, int BX>
 __device__ __forceinline__ int stage_k(int j, int wave, int lane) {
     const int i = 4 * wave + j;
     if (RC) {
         const int row = 8 * i + (lane >> 3), p = lane & 7;
         return (p ^ ((row >> 1) & 7)) * 8;
     }
-    return 2 * i + (lane >> 5);
+    constexpr int LPR = BX / 8;
+    return (64 / LPR) * i + lane / LPR;
 }
 
 template <int J0, int J1>
@@ -72,33 +75,34 @@ __device__ __forceinline__ void stage_dma(const bf16_t* base, const int (&voff)[
 }
 
 // Last, partial K-tile: same image through registers, reduction indices >= kvalid are zero.
-template <bool RC>
+template <bool RC, int BX>
 __device__ __forceinline__ void stage_tail(const bf16_t* base, const int (&voff)[4], char* tile, int wave, int lane,
                                            int kvalid) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (stage_k<RC>(j, wave, lane) < kvalid) v = *reinterpret_cast<const u32x4*>(base + voff[j]);
+        if (stage_k<RC, BX>(j, wave, lane) < kvalid) v = *reinterpret_cast<const u32x4*>(base + voff[j]);
         *reinterpret_cast<u32x4*>(tile + (4 * wave + j) * 1024 + lane * 16) = v;
     }
 }
 
 // Fragment of v_mfma_f32_32x32x16_bf16 for rows/cols [xt, xt+32) and reduction step ks (16 wide):
 // lane l holds x = xt + (l & 31), k = 16*ks + 8*(l >> 5) + 0..7.
-template <bool RC>
+template <bool RC, int BX>
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int xt, int ks, int lane) {
     if (RC) {
         const int row = xt + (lane & 31);
         const int c = (2 * ks + (lane >> 5)) ^ ((row >> 1) & 7);
         return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (c << 4));
     } else {
+        constexpr int RB = BX * 2;  // bytes per k-row
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3, h = lane >> 5;
         const int k = 16 * ks + 8 * h + q;
         const int xb = (xt + 16 * (g & 1) + 4 * p4) * 2;
-        const int off = k * 512 + ((((xb >> 6) ^ q) & 7) << 6) + (xb & 63);
+        const int off = k * RB + ((((xb >> 6) ^ q) & (RB / 64 - 1)) << 6) + (xb & 63);
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * 512));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * RB));
         s16x8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -106,30 +110,22 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int xt, int ks, in
     }
 }
 
-template <bool A_RC, bool B_RC>
+template <bool A_RC, bool B_RC, int BX, int MI>
 __device__ __forceinline__ void load_frags(const char* tA, const char* tB, int wm, int wn, int ks, int lane,
-                                           bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+                                           bf16x8 (&fa)[MI], bf16x8 (&fb)[2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_RC>(tB, wn * 64 + j * 32, ks, lane);
+    for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_RC, BX>(tB, wn * 64 + j * 32, ks, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_RC>(tA, wm * 128 + i * 32, ks, lane);
+    for (int i = 0; i < MI; ++i) fa[i] = read_frag<A_RC, BX>(tA, wm * (MI * 32) + i * 32, ks, lane);
 }
 
-template <typename F>
-__device__ __forceinline__ void mma_step(const bf16x8 (&fa)[4], const bf16x8 (&fb)[2], f32x16 (&acc)[4][2], F&& piece,
+template <int MI, typename F>
+__device__ __forceinline__ void mma_step(const bf16x8 (&fa)[MI], const bf16x8 (&fb)[2], f32x16 (&acc)[MI][2], F&& piece,
                                          int p0) {
     piece(p0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    piece(p0 + 1);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 2; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
@@ -137,27 +133,49 @@ __device__ __forceinline__ void mma_step(const bf16x8 (&fa)[4], const bf16x8 (&f
 }
 
 // One K-tile: the fragments of step ks+1 are read while step ks is multiplied (two register sets).
-// `piece(p)`, p = 0..7, issues one eighth of the iteration's LDS-DMA in front of each group of 4 MFMAs, so that a
-// wave never sits in a long run of VMEM issue while the memory pipeline is full.
-template <bool A_RC, bool B_RC, typename F>
+// `piece(p)`, p = 0..3, issues a quarter of the iteration's LDS-DMA (two instructions) in front of each MFMA group,
+// so that a wave never sits in a long run of VMEM issue while the memory pipeline is full (measured at NW = 8:
+// 980 TF; one instruction per 4 MFMAs 920; all eight up front 840).
+template <bool A_RC, bool B_RC, int BX, int MI, typename F>
 __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, int wm, int wn, int lane,
-                                             f32x16 (&acc)[4][2], F&& piece) {
-    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
-    load_frags<A_RC, B_RC>(tA, tB, wm, wn, 0, lane, fa0, fb0);
-    load_frags<A_RC, B_RC>(tA, tB, wm, wn, 1, lane, fa1, fb1);
-    mma_step(fa0, fb0, acc, piece, 0);
-    load_frags<A_RC, B_RC>(tA, tB, wm, wn, 2, lane, fa0, fb0);
-    mma_step(fa1, fb1, acc, piece, 2);
-    load_frags<A_RC, B_RC>(tA, tB, wm, wn, 3, lane, fa1, fb1);
-    mma_step(fa0, fb0, acc, piece, 4);
-    mma_step(fa1, fb1, acc, piece, 6);
+                                             f32x16 (&acc)[MI][2], F&& piece) {
+    bf16x8 fa0[MI], fb0[2], fa1[MI], fb1[2];
+    load_frags<A_RC, B_RC, BX, MI>(tA, tB, wm, wn, 0, lane, fa0, fb0);
+    load_frags<A_RC, B_RC, BX, MI>(tA, tB, wm, wn, 1, lane, fa1, fb1);
+    mma_step<MI>(fa0, fb0, acc, piece, 0);
+    load_frags<A_RC, B_RC, BX, MI>(tA, tB, wm, wn, 2, lane, fa0, fb0);
+    mma_step<MI>(fa1, fb1, acc, piece, 1);
+    load_frags<A_RC, B_RC, BX, MI>(tA, tB, wm, wn, 3, lane, fa1, fb1);
+    mma_step<MI>(fa0, fb0, acc, piece, 2);
+    mma_step<MI>(fa1, fb1, acc, piece, 3);
 }
 
-template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(NT) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n, int dbg) {
+// s_waitcnt vmcnt(4 * c): all but the c newest operand-tile loads (4 DMA instructions per wave each) have landed
+__device__ __forceinline__ void wait_loads(int c) {
+    switch (c) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    }
+}
+
+// Ring of NSLOT = 2*D + 1 operand-tile slots: while K-tile T is multiplied, the loads of tiles T+1 .. T+D-1 and A of
+// T+D are in flight or landed.  D = 2 for the 256x256 tile (5 x 32 KB), D = 4 for the 128x128 tile (9 x 16 KB): its
+// K-step is short (16 MFMAs per wave), so the ~1 us LDS-DMA round trip needs more tiles ahead of it.
+template <bool A_RC, bool B_RC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n, int dbg) {
+    constexpr int BX = 32 * NW;             // block tile edge: 256 or 128
+    constexpr int D = NW == 8 ? 2 : 4;
+    constexpr int NSLOT = 2 * D + 1;
+    constexpr int MI = NW / 2;              // MFMA tiles per wave along M
+    constexpr int WN = NW / 2;              // waves along N
+    constexpr int TILE_BYTES = BX * BK * 2; // one operand tile = one ring slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- workgroup -> (split, tile) with the blocks of one XCD on a compact panel
     int wg;
@@ -178,91 +196,144 @@ __global__ __launch_bounds__(NT) void gemm_wide_kernel(GemmArgs a, int tiles_m, 
         tm = first + u % gsz;
         tn = u / gsz;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BX, n0 = tn * BX;
     const int rbeg = split * a.r_per_split;
     const int rend = min(a.R, rbeg + a.r_per_split);
     const int rlen = max(rend - rbeg, 0);
     const int nfull = rlen / BK;
     const int ktail = rlen - nfull * BK;
-    const int nt = nfull + (ktail ? 1 : 0);
+    const int nt1 = nfull + (ktail ? 1 : 0);        // K-tiles of one segment
+    const int nt = a.A_lo ? 3 * nt1 : nt1;          // bf16x3: segments (hi,hi) (hi,lo) (lo,hi)
 
     // uniform tile bases (scalar registers) + 32-bit per-lane offsets
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A) + (A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0);
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B) + (B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0);
+    const int64_t offA = A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0;
+    const int64_t offB = B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0;
+    const bf16_t* Ah = reinterpret_cast<const bf16_t*>(a.A) + offA;
+    const bf16_t* Bh = reinterpret_cast<const bf16_t*>(a.B) + offB;
+    const bf16_t* Al = reinterpret_cast<const bf16_t*>(a.A_lo) + offA;
+    const bf16_t* Bl = reinterpret_cast<const bf16_t*>(a.B_lo) + offB;
     int voa[4], vob[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        voa[j] = stage_offset<A_RC>(j, a.lda, m0, a.M, wave, lane);
-        vob[j] = stage_offset<B_RC>(j, a.ldb, n0, a.N, wave, lane);
+        voa[j] = stage_offset<A_RC, BX>(j, a.lda, m0, a.M, wave, lane);
+        vob[j] = stage_offset<B_RC, BX>(j, a.ldb, n0, a.N, wave, lane);
     }
     const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
     const int64_t stepB = B_RC ? BK : (int64_t)BK * a.ldb;
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // load n: operand tile (n & 1 ? B : A) of K-tile n >> 1, into ring slot n % 5; `q` = which of the 4 DMA
-    // instructions (-1: all four).  A tail tile goes through registers in one piece.
-    auto issue = [&](int n, int slot, int q) {
-        if (dbg & 1) return;
-        const int t = n >> 1;
+    // ---- issue state: the next A tile and the next B tile to stage (segment, K-tile inside it, source pointer)
+    const int nseg = a.A_lo ? 3 : 1;
+    int segA = 0, tA = 0, segB = 0, tB = 0;
+    const bf16_t* pA = Ah;
+    const bf16_t* pB = Bh;
+    auto advA = [&]() {
+        ++tA;
+        pA += stepA;
+        if (tA == nt1) { tA = 0; ++segA; pA = (segA == 2) ? Al : Ah; }
+    };
+    auto advB = [&]() {
+        ++tB;
+        pB += stepB;
+        if (tB == nt1) { tB = 0; ++segB; pB = (segB == 1) ? Bl : Bh; }
+    };
+    // generic issue of the next A / B tile into `slot`; q = which half of its 4 DMA instructions (-1: all four).
+    // A partial (tail) tile goes through registers in one piece; past the last segment nothing is issued.
+    auto issueA = [&](int slot, int q) {
+        if ((dbg & 1) || segA >= nseg) return;
         char* dst = smem + slot * TILE_BYTES;
-        const bf16_t* src = (n & 1) ? B + t * stepB : A + t * stepA;
-        if (t < nfull) {
-            if (n & 1) {
-                if (q < 0 || q == 0) stage_dma<0, 1>(src, vob, dst, wave);
-                if (q < 0 || q == 1) stage_dma<1, 2>(src, vob, dst, wave);
-                if (q < 0 || q == 2) stage_dma<2, 3>(src, vob, dst, wave);
-                if (q < 0 || q == 3) stage_dma<3, 4>(src, vob, dst, wave);
-            } else {
-                if (q < 0 || q == 0) stage_dma<0, 1>(src, voa, dst, wave);
-                if (q < 0 || q == 1) stage_dma<1, 2>(src, voa, dst, wave);
-                if (q < 0 || q == 2) stage_dma<2, 3>(src, voa, dst, wave);
-                if (q < 0 || q == 3) stage_dma<3, 4>(src, voa, dst, wave);
-            }
-        } else if (t < nt && q <= 0) {
-            if (n & 1) stage_tail<B_RC>(src, vob, dst, wave, lane, ktail);
-            else stage_tail<A_RC>(src, voa, dst, wave, lane, ktail);
+        if (tA < nfull) {
+            if (q != 1) stage_dma<0, 2>(pA, voa, dst, wave);
+            if (q != 0) stage_dma<2, 4>(pA, voa, dst, wave);
+        } else if (q <= 0) {
+            stage_tail<A_RC, BX>(pA, voa, dst, wave, lane, ktail);
         }
     };
+    auto issueB = [&](int slot, int q) {
+        if ((dbg & 1) || segB >= nseg) return;
+        char* dst = smem + slot * TILE_BYTES;
+        if (tB < nfull) {
+            if (q != 1) stage_dma<0, 2>(pB, vob, dst, wave);
+            if (q != 0) stage_dma<2, 4>(pB, vob, dst, wave);
+        } else if (q <= 0) {
+            stage_tail<B_RC, BX>(pB, vob, dst, wave, lane, ktail);
+        }
+    };
+    // is virtual K-tile T staged by DMA (a full tile)?
+    auto is_dma = [&](int T) {
+        if (T >= nt) return false;
+        const int t = T - (T >= nt1 ? nt1 : 0) - (T >= 2 * nt1 ? nt1 : 0);
+        return t < nfull;
+    };
 
-    issue(0, 0, -1);
-    issue(1, 1, -1);
-    issue(2, 2, -1);
-    int sa = 0;  // slot of A_t; B_t is in the next one
-    for (int t = 0; t < nt; ++t) {
-        // loads 2t and 2t+1 must have landed; load 2t+2 (4 DMA instructions per wave) may stay in flight
-        if (t + 1 < nfull) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: loads 0 .. 2D-2 = tiles 0 .. D-2 (A and B) and A of tile D-1, into slots 0 .. 2D-2
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) {
+        issueA(2 * i, -1); advA();
+        issueB(2 * i + 1, -1); advB();
+    }
+    issueA(2 * D - 2, -1); advA();
+
+    // K-tiles [0, nfast): every tile up to D ahead exists and is a full tile -> branch-free steady state
+    const int nfast = max(0, ((ktail == 0) ? nt : (nseg == 1 ? nfull : 0)) - D);
+    int sa = 0;  // slot of A_T; B_T is in the next one
+    auto slot_of = [&](int d) { return sa + d >= NSLOT ? sa + d - NSLOT : sa + d; };
+    int T = 0;
+    for (; T < nfast; ++T) {
+        // loads 2T and 2T+1 must have landed; the 2D-3 newer ones stay in flight
+        wait_loads(2 * D - 3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int sb = sa + 1 >= NSLOT ? sa + 1 - NSLOT : sa + 1;
-        const int s3 = sa + 3 >= NSLOT ? sa + 3 - NSLOT : sa + 3;
-        const int s4 = sa + 4 >= NSLOT ? sa + 4 - NSLOT : sa + 4;
-        // loads 2t+3 and 2t+4 go to the slots tile t-1 occupied: every wave is past its reads of them
+        char* d3 = smem + slot_of(2 * D - 1) * TILE_BYTES;  // the slots tile T-1 occupied: every wave is past
+        char* d4 = smem + slot_of(2 * D) * TILE_BYTES;      // its reads of them
         auto piece = [&](int p) {
-            if (dbg & 4) {
-                if (p == 0) { issue(2 * t + 3, s3, -1); issue(2 * t + 4, s4, -1); }
-                return;
-            }
-            // two DMA instructions in front of every group of 8 MFMAs (measured: 980 TF; one per 4 MFMAs 920,
-            // all eight up front 840)
-            if (p & 1) return;
-            if (p < 4) { issue(2 * t + 3, s3, p); issue(2 * t + 3, s3, p + 1); }
-            else { issue(2 * t + 4, s4, p - 4); issue(2 * t + 4, s4, p - 3); }
+            if (dbg & 1) return;
+            if (p == 0) stage_dma<0, 2>(pB, vob, d3, wave);
+            if (p == 1) stage_dma<2, 4>(pB, vob, d3, wave);
+            if (p == 2) stage_dma<0, 2>(pA, voa, d4, wave);
+            if (p == 3) stage_dma<2, 4>(pA, voa, d4, wave);
         };
         if (!(dbg & 2)) {
-            compute_tile<A_RC, B_RC>(smem + sa * TILE_BYTES, smem + sb * TILE_BYTES, wm, wn, lane, acc, piece);
+            compute_tile<A_RC, B_RC, BX, MI>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc,
+                                             piece);
         } else {
-            piece(0); piece(1); piece(2); piece(3); piece(4); piece(5); piece(6); piece(7);
+            piece(0); piece(1); piece(2); piece(3);
         }
-        sa = sa + 2 >= NSLOT ? sa + 2 - NSLOT : sa + 2;
+        advB();
+        advA();
+        sa = slot_of(2);
+    }
+    // the rest: tails, segment ends, drain
+    for (; T < nt; ++T) {
+        int inflight = 0;
+#pragma unroll
+        for (int n = 2; n <= 2 * D - 2; ++n) inflight += is_dma(T + (n >> 1)) ? 1 : 0;
+        wait_loads(inflight);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int s3 = slot_of(2 * D - 1), s4 = slot_of(2 * D);
+        auto piece = [&](int p) {
+            if (p < 2) issueB(s3, p);
+            else issueA(s4, p - 2);
+        };
+        if (!(dbg & 2)) {
+            compute_tile<A_RC, B_RC, BX, MI>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc,
+                                             piece);
+        } else {
+            piece(0); piece(1); piece(2); piece(3);
+        }
+        advB();
+        advA();
+        sa = slot_of(2);
     }
 
     // ---- epilogue: C = alpha * acc + bias, transposed through LDS for 16-byte-per-lane stores
@@ -281,7 +352,7 @@ __global__ __launch_bounds__(NT) void gemm_wide_kernel(GemmArgs a, int tiles_m, 
             if (col4 + c < a.N) bv[c] = a.bias[col4 + c];
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < MI / 2; ++half) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -296,7 +367,7 @@ __global__ __launch_bounds__(NT) void gemm_wide_kernel(GemmArgs a, int tiles_m, 
         for (int rr = 0; rr < 16; ++rr) {
             const int r = rr * 4 + (lane >> 4);
             f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
-            const int row = m0 + wm * 128 + half * 64 + r;
+            const int row = m0 + wm * (MI * 32) + half * 64 + r;
             if (row < a.M) {
                 float* dst = C + (int64_t)row * a.ldc + col4;
                 if (vec_ok) {
@@ -317,32 +388,45 @@ __global__ __launch_bounds__(NT) void gemm_wide_kernel(GemmArgs a, int tiles_m, 
 
 }  // namespace wide
 
-bool wide_eligible(int layout, int dtype, const GemmArgs& a) {
-    if (dtype != C2_BF16) return false;
-    if (!aligned16(a.A) || !aligned16(a.B) || (a.lda & 7) || (a.ldb & 7) || (a.R & 7)) return false;
+// 0 = not taken by this file; 256 / 128 = block-tile edge.
+int wide_tile(int dtype, const GemmArgs& a) {
+    if (dtype != C2_BF16 && dtype != C2_BF16X3P) return 0;
+    if (!aligned16(a.A) || !aligned16(a.B) || (a.lda & 7) || (a.ldb & 7) || (a.R & 7)) return 0;
+    if (dtype == C2_BF16X3P) {
+        if (!aligned16(a.A_lo) || !aligned16(a.B_lo)) return 0;
+        return (a.R >= 64 && a.M >= 1 && a.N >= 1) ? 128 : 0;
+    }
     // worth a 256x256 tile: a gene-width problem
-    if ((int64_t)a.M * a.N < 256ll * 256 * 32 || a.R < 256 || a.M < 192 || a.N < 192) return false;
-    return true;
+    if ((int64_t)a.M * a.N < 256ll * 256 * 32 || a.R < 256 || a.M < 192 || a.N < 192) return 0;
+    return 256;
 }
 
-int launch_gemm_wide(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+template <int NW>
+static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream, int dbg) {
     using namespace wide;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    constexpr int BX = 32 * NW;
+    constexpr int LDS = (NW == 8 ? 5 : 9) * BX * BK * 2;
+    const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;
     const dim3 grid(tiles_m * tiles_n * nslab);
-    static const int dbg = getenv("C2_GEMM_DBG") ? atoi(getenv("C2_GEMM_DBG")) : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     if (layout == 0)
-        hipLaunchKernelGGL((gemm_wide_kernel<true, true>), grid, dim3(NT), LDS_BYTES, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
     else if (layout == 1)
-        hipLaunchKernelGGL((gemm_wide_kernel<true, false>), grid, dim3(NT), LDS_BYTES, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
     else
-        hipLaunchKernelGGL((gemm_wide_kernel<false, false>), grid, dim3(NT), LDS_BYTES, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
+}
+
+int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {
+    static const int dbg = getenv("C2_GEMM_DBG") ? atoi(getenv("C2_GEMM_DBG")) : 0;
+    if (tile == 256) launch_nw<8>(layout, a, nslab, stream, dbg);
+    else launch_nw<4>(layout, a, nslab, stream, dbg);
     return 0;
 }
 

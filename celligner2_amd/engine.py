@@ -44,6 +44,8 @@ class StepEngine:
         self._ws = {}
         self._shadow = {}
         self._shadow_ver = {}
+        self._wplanes = {}   # bf16x3: (version, [2,N,K] bf16 planes) of the fp32 weights of the narrow layers
+        self._aplanes = {}   # bf16x3: planes of this step's fp32 activations / gradients, by (data_ptr, shape)
         self.grad = {}
         self._touched = set()
         self.world_size, self.rank = 1, 0
@@ -175,12 +177,59 @@ class StepEngine:
         return out
 
     # ------------------------------------------------------------------ helpers
+    # bf16 mode, narrow (fp32-operand) GEMMs: both operands are split ONCE into bf16 planes (hi, lo) and multiplied
+    # as three bf16 products by the LDS-DMA kernel (C2_BF16X3P); shapes it cannot take stay on the in-kernel split.
+    def _planes_of(self, t):
+        key = (t.data_ptr(), tuple(t.shape))
+        pl = self._aplanes.get(key)
+        if pl is None:
+            pl = ops.split_bf16(t, self.buf(("pl", len(self._aplanes)), (2,) + tuple(t.shape), torch.bfloat16))
+            self._aplanes[key] = pl
+        return pl
+
+    def _wplanes_of(self, name):
+        p = self.p[name]
+        c = self._wplanes.get(name)
+        if c is None or c[0] != p._version or c[1].shape[1:] != p.shape:
+            pl = c[1] if (c is not None and c[1].shape[1:] == p.shape) else None
+            c = (p._version, ops.split_bf16(p.detach(), pl))
+            self._wplanes[name] = c
+        return c[1]
+
+    def _pair(self, x, y, M, N, R, wx=None, wy=None):
+        """Operand pair of one GEMM ([M,N] output reduced over R): planes when both are fp32 in bf16x3 mode and the
+        shape allows, else unchanged.  wx / wy: parameter name when that operand is a weight.  Returns (x, y, planes)."""
+        if not (self.x3 and x.dtype == F32 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous()
+                and ops.planes_ok(M, N, R, (x.shape[1], y.shape[1]))):
+            return x, y, False
+        px = self._wplanes_of(wx) if wx else self._planes_of(x)
+        py = self._wplanes_of(wy) if wy else self._planes_of(y)
+        return px, py, True
+
+    def _fwd(self, a, wname, y, bias=None):
+        """y = a @ W^T (+ bias), unsplit."""
+        w = self.weight(wname)
+        a2, w2, _ = self._pair(a, w, a.shape[0], w.shape[0], w.shape[1], wy=wname)
+        ops.linear_fwd(a2, w2, y, bias=bias, x3=self.x3)
+
+    def _dgrad(self, dy, wname, out_slabs, alpha=None):
+        w = self.weight(wname)
+        d2, w2, _ = self._pair(dy, w, dy.shape[0], w.shape[1], w.shape[0], wy=wname)
+        ops.linear_dgrad(d2, w2, out_slabs, nslab=out_slabs.shape[0], alpha=alpha, x3=self.x3)
+
+    def _dgrad_nslab(self, dy, wname):
+        w = self.weight(wname)
+        M, K, R = dy.shape[0], w.shape[1], w.shape[0]
+        _, _, pl = self._pair(dy, w, M, K, R, wy=wname)
+        return ops.pick_nslab(M, K, R, dy.dtype, self.x3, planes=pl)
+
     def _linear_slabs(self, key, a, wname, B):
         w = self.weight(wname)
         N, K = w.shape
-        ns = ops.pick_nslab(B, N, K, a.dtype, self.x3)
+        a2, w2, pl = self._pair(a, w, B, N, K, wy=wname)
+        ns = ops.pick_nslab(B, N, K, a.dtype, self.x3, planes=pl)
         y = self.buf(key + ".Y", (ns, B, N))
-        ops.linear_fwd(a, w, y, nslab=ns, x3=self.x3)
+        ops.linear_fwd(a2, w2, y, nslab=ns, x3=self.x3)
         return y
 
     def _wgrad(self, dy, a, name, alpha=None):
@@ -188,12 +237,13 @@ class StepEngine:
         that the launch fills the chip, then sums them (deterministic)."""
         g = self.gbuf(name)
         N, K = g.shape
-        ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
+        dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
+        ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3, planes=pl)
         if ns == 1:
-            ops.linear_wgrad(dy, a, g, alpha=alpha, x3=self.x3)
+            ops.linear_wgrad(dy2, a2, g, alpha=alpha, x3=self.x3)
         else:
             slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
-            ops.linear_wgrad(dy, a, slabs, nslab=ns, alpha=alpha, x3=self.x3)
+            ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
 
     def _block_fwd(self, blk, a, cond, masks, train, save):
@@ -230,12 +280,10 @@ class StepEngine:
                                self.gbuf(blk.wc) if need_c else None, ws)
         if not need_da:
             return None
-        w = self.weight(blk.w)
-        K = w.shape[1]
+        K = self.p[blk.w].shape[1]
         if out_slabs is None:
-            ns = ops.pick_nslab(B, K, H, dh.dtype, self.x3)
-            out_slabs = self.buf(blk.name + ".da", (ns, B, K))
-        ops.linear_dgrad(dh, w, out_slabs, nslab=out_slabs.shape[0], x3=self.x3)
+            out_slabs = self.buf(blk.name + ".da", (self._dgrad_nslab(dh, blk.w), B, K))
+        self._dgrad(dh, blk.w, out_slabs)
         return out_slabs
 
     # ------------------------------------------------------------------ forward
@@ -250,6 +298,7 @@ class StepEngine:
         Bn = B * self.world_size
         inv_B = 1.0 / Bn
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
+        self._aplanes = {}
         losses = self.buf("losses", (4,))
         losses.zero_()
         status = self.buf("status", (2,), torch.int32)
@@ -275,10 +324,8 @@ class StepEngine:
         self._henc = a
         L = cfg["latent"]
         mulv = self.buf("mulv", (2, B, L))
-        ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
-                       bias=self.p["encoder.mean_encoder.bias"].detach(), x3=self.x3)
-        ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
-                       bias=self.p["encoder.log_var_encoder.bias"].detach(), x3=self.x3)
+        self._fwd(a, "encoder.mean_encoder.weight", mulv[0], bias=self.p["encoder.mean_encoder.bias"].detach())
+        self._fwd(a, "encoder.log_var_encoder.weight", mulv[1], bias=self.p["encoder.log_var_encoder.bias"].detach())
         z32 = self.buf("z32", (B, L))
         red_ws = self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),))
         zdt = self.dec[0].gt
@@ -294,7 +341,7 @@ class StepEngine:
         self._dlast = d
         y1 = self._ws["dec0.act"]
         logits = self.buf("logits", (B, G))
-        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach(), x3=self.x3)
+        self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
         # ---- reconstruction loss (+ its unit-upstream gradient)
         dlogits = self.buf("dlogits", (B, G), self.head_t)
         if cfg["recon_loss"] == "nb":
@@ -320,8 +367,7 @@ class StepEngine:
             P = cfg["n_predictors"]
             if P > 0:
                 u = self.buf("u", (B, P))
-                ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
-                               bias=self.p["classifier.classifier.0.bias"].detach(), x3=self.x3)
+                self._fwd(c, "classifier.classifier.0.weight", u, bias=self.p["classifier.classifier.0.bias"].detach())
                 du = self.buf("du", (B, P), self.gemm_dtype("classifier.classifier.0.weight"))
                 ops.classifier_loss(u, classes, cfg["betaclass"], losses[3:4], du, red_ws)
         # ---- MMD over the (global) batch
@@ -366,11 +412,9 @@ class StepEngine:
         if rq(hb):
             ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
             ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
-        w = self.weight(hw)
-        H1 = w.shape[1]
-        ns = ops.pick_nslab(B, H1, G, dlogits.dtype, self.x3)
-        dd = self.buf("dhead.da", (ns, B, H1))
-        ops.linear_dgrad(dlogits, w, dd, nslab=ns, alpha=gr, x3=self.x3)
+        H1 = self.p[hw].shape[1]
+        dd = self.buf("dhead.da", (self._dgrad_nslab(dlogits, hw), B, H1))
+        self._dgrad(dlogits, hw, dd, alpha=gr)
         if cfg["recon_loss"] == "nb" and rq("theta"):
             gt = self.gbuf("theta")
             gt.zero_()
@@ -382,9 +426,14 @@ class StepEngine:
         n_cls_slab = 1 if (self._has_cls and cfg["n_predictors"] > 0) else 0
         for i in range(len(self.dec) - 1, 0, -1):
             dd = self._block_bwd(self.dec[i], dd, self._dec_in[i], cond, masks, True)
-        dz_all = self.buf("dz.all", (1 + n_cls_slab, B, L))
+        # d(z): slabs of the decoder-first-layer dgrad (a short-and-narrow GEMM: split so that it fills the chip)
+        # followed by one slab from the classifier branch; the reparameterisation backward sums them
+        H0 = self.p[self.dec[0].w].shape[0]
+        nz = ops.pick_nslab(B, L, H0, self.dec[0].gt, self.x3,
+                            planes=self.x3 and self.dec[0].gt == F32 and ops.planes_ok(B, L, H0, (H0, L)))
+        dz_all = self.buf("dz.all", (nz + n_cls_slab, B, L))
         on_y = cfg["use_mmd"] and cfg["mmd_on"] != "z"
-        self._block_bwd(self.dec[0], dd, self._dec_in[0], cond, masks, True, out_slabs=dz_all[0:1],
+        self._block_bwd(self.dec[0], dd, self._dec_in[0], cond, masks, True, out_slabs=dz_all[0:nz],
                         extra=self._dfeat if on_y else None, extra_scale=gm if on_y else None)
         # ---- classifier branch
         if n_cls_slab:
@@ -396,10 +445,10 @@ class StepEngine:
                 ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
                 ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
             dc = self.buf("dcls.da", (1, B, self._clast.shape[1]))
-            ops.linear_dgrad(du, self.weight(cw), dc, alpha=gc, x3=self.x3)
+            self._dgrad(du, cw, dc, alpha=gc)
             for i in range(len(self.cls) - 1, 0, -1):
                 dc = self._block_bwd(self.cls[i], dc, self._cls_in[i], None, masks, True)
-            self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[1:2])
+            self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[nz:nz + 1])
         # ---- reparameterisation + KL
         on_z = cfg["use_mmd"] and cfg["mmd_on"] == "z"
         mulv = self._ws["mulv"]
@@ -415,7 +464,7 @@ class StepEngine:
             if rq(nm + ".bias"):
                 ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
                 ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
-            ops.linear_dgrad(dml[k], self.weight(nm + ".weight"), da[k:k + 1], x3=self.x3)
+            self._dgrad(dml[k], nm + ".weight", da[k:k + 1])
         # ---- encoder blocks
         need = self._first_trainable_enc()
         for i in range(len(self.enc) - 1, -1, -1):
@@ -448,15 +497,14 @@ class StepEngine:
             ops.prep_input(x, xin, cfg["applylog"])  # get_latent applies the log for every recon loss (:398-399)
         else:
             xin = x
+        self._aplanes = {}
         a = xin
         for blk in self.enc:
             a = self._block_fwd(blk, a, cond, {}, False, False)
         L = cfg["latent"]
         mulv = self.buf("mulv", (2, B, L))
-        ops.linear_fwd(a, self.weight("encoder.mean_encoder.weight"), mulv[0],
-                       bias=self.p["encoder.mean_encoder.bias"].detach(), x3=self.x3)
-        ops.linear_fwd(a, self.weight("encoder.log_var_encoder.weight"), mulv[1],
-                       bias=self.p["encoder.log_var_encoder.bias"].detach(), x3=self.x3)
+        self._fwd(a, "encoder.mean_encoder.weight", mulv[0], bias=self.p["encoder.mean_encoder.bias"].detach())
+        self._fwd(a, "encoder.log_var_encoder.weight", mulv[1], bias=self.p["encoder.log_var_encoder.bias"].detach())
         z = None
         if eps is not None:
             z = self.buf("z32", (B, L))
@@ -467,25 +515,26 @@ class StepEngine:
         return mulv[0], mulv[1], z
 
     def classify(self, z):
+        self._aplanes = {}
         c = self.as_dtype("z.cls", z, self.cls[0].gt)
         for blk in self.cls:
             c = self._block_fwd(blk, c, None, {}, False, False)
         P = self.cfg["n_predictors"]
         u = self.buf("u", (z.shape[0], P))
         if P > 0:
-            ops.linear_fwd(c, self.weight("classifier.classifier.0.weight"), u,
-                           bias=self.p["classifier.classifier.0.bias"].detach(), x3=self.x3)
+            self._fwd(c, "classifier.classifier.0.weight", u, bias=self.p["classifier.classifier.0.bias"].detach())
         return u
 
     def decode(self, z, cond):
         """Forward-only decoder (celligner2.py:411-420): returns (output, y1) like Decoder.forward."""
+        self._aplanes = {}
         d = self.as_dtype("z.dec", z, self.dec[0].gt)
         for blk in self.dec:
             d = self._block_fwd(blk, d, cond, {}, False, False)
         B = z.shape[0]
         G = self.cfg["input_dim"]
         logits = self.buf("logits", (B, G))
-        ops.linear_fwd(d, self.weight(self.head + ".weight"), logits, bias=self.p[self.head + ".bias"].detach(), x3=self.x3)
+        self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
         return logits, self._ws["dec0.act"]
 
     def check_status(self):

@@ -35,7 +35,7 @@ class _GemmTimer:
 
 
 def _gemm_code(dtype, x3):
-    return 2 if (x3 and dtype == torch.float32) else dt_code(dtype)
+    return L.F32X3 if (x3 and dtype == torch.float32) else dt_code(dtype)
 
 
 def _row_major(t, name):
@@ -44,18 +44,47 @@ def _row_major(t, name):
     return t.stride(0)
 
 
-def gemm_tile(dtype, M, N, R, x3=False):
-    """Block-tile edge the library uses for an [M,N] output reduced over R with operands of `dtype`."""
-    return int(lib.c2_gemm_tile(_gemm_code(dtype, x3), M, N, R))
+def _operand(t, name, x3):
+    """(2-D shape, leading dimension, dtype code) of a GEMM operand: a row-major matrix, or the two bf16 planes
+    [2, rows, cols] (hi, lo) that split_bf16 makes of an fp32 matrix (dtype C2_BF16X3P)."""
+    if t.dim() == 3:
+        if t.dtype != torch.bfloat16 or t.shape[0] != 2 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise L.C2Error(f"{name}: planes must be a [2, rows, cols] bf16 tensor with plane stride rows*ld")
+        return tuple(t.shape[1:]), t.stride(1), L.BF16X3P
+    return tuple(t.shape), _row_major(t, name), _gemm_code(t.dtype, x3)
 
 
-def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16):
+def split_bf16(src, out=None):
+    """fp32 [rows, cols] -> bf16 planes [2, rows, cols]: hi = bf16(x), lo = bf16(x - hi)."""
+    L.require_gpu(src)
+    rows, cols = src.shape
+    assert src.dtype == torch.float32
+    if out is None:
+        out = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=src.device)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (2, rows, cols) and out.is_contiguous()
+    check(lib.c2_split_bf16(ptr(src), rows, cols, _row_major(src, "src"), ptr(out), cols, stream()))
+    return out
+
+
+def gemm_tile(dtype, M, N, R, x3=False, planes=False):
+    """Block-tile edge the library uses for an [M,N] output reduced over R with operands of `dtype`
+    (0: bf16 planes cannot take this shape)."""
+    code = L.BF16X3P if planes else _gemm_code(dtype, x3)
+    return int(lib.c2_gemm_tile(code, M, N, R))
+
+
+def planes_ok(M, N, R, lds=()):
+    """Can an [M,N] = sum over R GEMM run on bf16 planes (LDS-DMA kernel)?  lds: the operands' leading dimensions."""
+    return gemm_tile(None, M, N, R, planes=True) > 0 and all(int(x) % 8 == 0 for x in lds)
+
+
+def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False):
     """Number of slabs a reduction of length R is split into for an [M,N] output, so that the launch fills the
-    256 CUs: >= ~2 blocks per CU of the 128x128 kernel, one 512-thread block per CU of the 256x256 kernel."""
-    tile = gemm_tile(dtype, M, N, R, x3)
+    256 CUs: >= ~2 blocks per CU of the register-staged 128x128 kernel, one block per CU of the LDS-DMA kernels."""
+    tile = gemm_tile(dtype, M, N, R, x3, planes)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
-    bk = 64 if dtype != torch.float32 else 32
-    target = 256 if tile == 256 else 512
+    bk = 64 if (planes or dtype != torch.float32) else 32
+    target = 256 if (tile == 256 or planes) else 512
     if tiles >= target or R <= 4 * bk:
         return 1
     n = min(max_slab, (target + tiles - 1) // tiles, max(1, R // (4 * bk)))
@@ -70,50 +99,50 @@ def prep_input(x, out, apply_log):
 
 
 def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
-    """y[s] = a @ w.T (+bias).  y: [M,N] or [nslab,M,N] fp32."""
+    """y[s] = a @ w.T (+bias).  y: [M,N] or [nslab,M,N] fp32.  a / w: matrices of one dtype, or bf16 planes."""
     L.require_gpu(a, w, y)
-    M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and a.dtype == w.dtype and y.dtype == torch.float32
+    (M, K), lda, code = _operand(a, "a", x3)
+    (N, K2), ldw, code_w = _operand(w, "w", x3)
+    assert K2 == K and code == code_w and y.dtype == torch.float32
     y2 = y if y.dim() == 2 else y[0]
     assert tuple(y2.shape) == (M, N)
     ss = y.stride(0) if y.dim() == 3 else 0
     assert (y.dim() == 3 and y.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_fwd(ptr(a), _row_major(a, "a"), ptr(w), _row_major(w, "w"), _gemm_code(a.dtype, x3), M, N, K,
-                                ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
+        check(lib.c2_linear_fwd(ptr(a), lda, ptr(w), ldw, code, M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss,
+                                ptr(bias), stream()))
     return y
 
 
 def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     """da[s] = alpha * dy @ w.   dy [M,N], w [N,K], da [M,K] or [nslab,M,K]."""
     L.require_gpu(dy, w, da)
-    M, N = dy.shape
-    K = w.shape[1]
-    assert w.shape[0] == N and dy.dtype == w.dtype and da.dtype == torch.float32
+    (M, N), lddy, code = _operand(dy, "dy", x3)
+    (N2, K), ldw, code_w = _operand(w, "w", x3)
+    assert N2 == N and code == code_w and da.dtype == torch.float32
     d2 = da if da.dim() == 2 else da[0]
     assert tuple(d2.shape) == (M, K)
     ss = da.stride(0) if da.dim() == 3 else 0
     assert (da.dim() == 3 and da.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_dgrad(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), _gemm_code(dy.dtype, x3), M, N,
-                                  K, ptr(da), _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
+        check(lib.c2_linear_dgrad(ptr(dy), lddy, ptr(w), ldw, code, M, N, K, ptr(da), _row_major(d2, "da"), nslab, ss,
+                                  ptr(alpha), stream()))
     return da
 
 
 def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False):
     """dw[s] = alpha * dy.T @ a.   dy [M,N], a [M,K], dw [N,K] or [nslab,N,K]."""
     L.require_gpu(dy, a, dw)
-    M, N = dy.shape
-    K = a.shape[1]
-    assert a.shape[0] == M and dy.dtype == a.dtype and dw.dtype == torch.float32
+    (M, N), lddy, code = _operand(dy, "dy", x3)
+    (M2, K), lda, code_a = _operand(a, "a", x3)
+    assert M2 == M and code == code_a and dw.dtype == torch.float32
     d2 = dw if dw.dim() == 2 else dw[0]
     assert tuple(d2.shape) == (N, K)
     ss = dw.stride(0) if dw.dim() == 3 else 0
     assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_wgrad(ptr(dy), _row_major(dy, "dy"), ptr(a), _row_major(a, "a"), _gemm_code(dy.dtype, x3), M, N,
-                                  K, ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
+        check(lib.c2_linear_wgrad(ptr(dy), lddy, ptr(a), lda, code, M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
+                                  ptr(alpha), stream()))
     return dw
 
 

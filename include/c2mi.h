@@ -34,6 +34,11 @@ extern "C" {
  * bf16 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative product error at 3/16 of the
  * fp32-MFMA cost (gfx950 has no TF32).  Used for the narrow hidden-layer GEMMs of bf16 mode. */
 #define C2_F32X3 2
+/* GEMM entry points only: the same bf16x3 product with the split done ONCE by the producer: each operand pointer
+ * addresses two bf16 planes [2][rows][ld] (hi, then lo = x - hi; c2_split_bf16), rows = the operand's own row
+ * count.  Staged by LDS-DMA like C2_BF16.  Needs 16-byte aligned planes, ld % 8 == 0 and a reduction length that
+ * is a multiple of 8 and >= 64 (c2_gemm_tile returns 0 otherwise). */
+#define C2_BF16X3P 3
 
 #define C2_MMD_MAX_PARTS 64 /* max distinct condition rows per batch for the MMD partition */
 
@@ -66,8 +71,13 @@ int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, in
 
 /* Block-tile edge (128 or 256) the three GEMM entry points above use for operand dtype `dtype` and an
  * [M,N] output reduced over R: callers size `nslab` from it so that a launch fills the 256 CUs.
+ * 0 = this dtype cannot take the shape (C2_BF16X3P only).
  * (No counterpart in the reference: torch picks its own BLAS blocking.) */
 int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R);
+
+/* fp32 [rows, cols] -> two bf16 planes dst[0] = hi = bf16(x), dst[1] = lo = bf16(x - hi); dst is [2][rows][ldd].
+ * Producer side of C2_BF16X3P (no counterpart in the reference, which multiplies in fp32). */
+int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd, void* stream);
 
 /* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
 int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);

@@ -449,3 +449,39 @@ def test_linear_bf16x3_mode(M, N, K):
     dw = torch.empty(2, N, K, device=DEV)
     ops.linear_wgrad(tdy, ta, dw, nslab=2, x3=True)
     assert rel(dw.sum(0), dy64.T @ a64) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 1024), (1000, 64, 520), (136, 200, 72), (512, 1024, 64)])
+def test_linear_bf16_planes(M, N, K):
+    """C2_BF16X3P: operands pre-split into bf16 planes (c2_split_bf16), three products on the 128x128 LDS-DMA kernel;
+    same ~2^-16 product error as the in-kernel split, ragged tiles, reduction tails, split reductions, bias."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
+    ta = torch.randn(M, K, generator=g).to(DEV)
+    tw = torch.randn(N, K, generator=g).to(DEV)
+    tdy = torch.randn(M, N, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    pa, pw, pdy = ops.split_bf16(ta), ops.split_bf16(tw), ops.split_bf16(tdy)
+    # the planes reproduce the operand to ~2^-17
+    assert float((pa[0].float() + pa[1].float() - ta).abs().max() / ta.abs().max()) < 2e-5
+    a64, w64, dy64 = ta.double(), tw.double(), tdy.double()
+    relt = lambda got, want: float((got.double() - want).abs().max() / want.abs().max())  # noqa: E731
+    assert ops.planes_ok(M, N, K, (K, K))
+    y = torch.full((M, N), float("nan"), device=DEV)
+    ops.linear_fwd(pa, pw, y, bias=bias)
+    assert relt(y, a64 @ w64.T + bias.double()) < 5e-5
+    ys = torch.full((3, M, N), float("nan"), device=DEV)
+    ops.linear_fwd(pa, pw, ys, nslab=3)
+    assert relt(ys.sum(0), a64 @ w64.T) < 5e-5
+    alpha = torch.tensor([0.5], device=DEV)
+    if ops.planes_ok(M, K, N, (N, K)):
+        da = torch.full((2, M, K), float("nan"), device=DEV)
+        ops.linear_dgrad(pdy, pw, da, nslab=2, alpha=alpha)
+        assert relt(da.sum(0), 0.5 * dy64 @ w64) < 5e-5
+    if ops.planes_ok(N, K, M, (N, K)):
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        ops.linear_wgrad(pdy, pa, dw)
+        assert relt(dw, dy64.T @ a64) < 5e-5
+        dws = torch.full((4, N, K), float("nan"), device=DEV)
+        ops.linear_wgrad(pdy, pa, dws, nslab=4)
+        assert relt(dws.sum(0), dy64.T @ a64) < 5e-5
