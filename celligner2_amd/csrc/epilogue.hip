@@ -378,33 +378,44 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const int64_t* __restrict__ cond, const int64_t* __restrict__ classes, int64_t G, int C, int P,
     const int64_t* __restrict__ idx, float* __restrict__ x_out, uint8_t* __restrict__ goodloc_out,
     float* __restrict__ sf_out, int64_t* __restrict__ cond_out, int64_t* __restrict__ classes_out,
-    TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok) {
+    TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin) {
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
     const float* xs = X + src * G;
-    float* xd = x_out + r * G;
+    float* xd = x_out ? x_out + r * G : nullptr;
+    const bool copy_good = goodloc && goodloc_out;
     if (vec_ok) {
         const int64_t gv = G >> 2;
         for (int64_t c = threadIdx.x; c < gv; c += 256) {
             f32x4 v = reinterpret_cast<const f32x4*>(xs)[c];
-            reinterpret_cast<f32x4*>(xd)[c] = v;
+            if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
             if (xin_out) {
+                f32x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = apply_log ? logf(1.0f + v[e]) : v[e];
-                    st_from_f32<TX>(xin_out + r * ldxin + c * 4 + e, t);
+                for (int e = 0; e < 4; ++e) t[e] = apply_log ? logf(1.0f + v[e]) : v[e];
+                TX* dst = xin_out + r * ldxin + c * 4;
+                if (sizeof(TX) == 2 && vec_xin) {
+                    u32x2 pk;
+                    pk[0] = (unsigned)f2bf(t[0]) | ((unsigned)f2bf(t[1]) << 16);
+                    pk[1] = (unsigned)f2bf(t[2]) | ((unsigned)f2bf(t[3]) << 16);
+                    *reinterpret_cast<u32x2*>(dst) = pk;
+                } else if (sizeof(TX) == 4 && vec_xin) {
+                    *reinterpret_cast<f32x4*>(dst) = t;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st_from_f32<TX>(dst + e, t[e]);
                 }
             }
-            if (goodloc)
+            if (copy_good)
                 reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] =
                     reinterpret_cast<const unsigned int*>(goodloc + src * G)[c];
         }
     } else {
         for (int64_t c = threadIdx.x; c < G; c += 256) {
             const float v = xs[c];
-            xd[c] = v;
+            if (xd) xd[c] = v;
             if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, apply_log ? logf(1.0f + v) : v);
-            if (goodloc) goodloc_out[r * G + c] = goodloc[src * G + c];
+            if (copy_good) goodloc_out[r * G + c] = goodloc[src * G + c];
         }
     }
     if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
@@ -636,24 +647,25 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
                               float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
                               int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
                               void* stream) {
-    C2_CHECK(X && idx && x_out, "null pointer");
-    C2_CHECK(!goodloc || goodloc_out, "goodloc_out missing");
+    C2_CHECK(X && idx, "null pointer");
+    C2_CHECK(x_out || xin_out, "nothing to write: x_out and xin_out are both NULL");
     C2_CHECK(!sizefactor || sf_out, "sf_out missing");
     C2_CHECK(!cond || cond_out, "cond_out missing");
     C2_CHECK(!classes || classes_out, "classes_out missing");
     C2_CHECK(!xin_out || ldxin >= G, "ldxin too small");
     if (n == 0 || G == 0) return 0;
-    const int vec_ok = (G % 4 == 0) && aligned16(X) && aligned16(x_out) &&
-                       (!goodloc || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0));
+    const int vec_ok = (G % 4 == 0) && aligned16(X) && (!x_out || aligned16(x_out)) &&
+                       (!(goodloc && goodloc_out) || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0));
+    const int vec_xin = xin_out && aligned16(xin_out) && (ldxin % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (xin_out && xin_dtype == C2_BF16)
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok);
+                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (float*)xin_out, ldxin, apply_log, vec_ok);
+                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin);
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -85,6 +85,7 @@ struct NbArgs {
     float* part_loss;  // [ngroups]
     int32_t* status;
     const float* lgx;  // optional [B]: sum_g goodloc * lgamma(x+1) of each row (a constant of the data), or NULL
+    const int64_t* ridx;  // optional [B]: row b of the batch is row ridx[b] of x / goodloc (resident dataset), or NULL
     int64_t ldl, ldx, ldg, lddl, B, G;
     int C;
     float inv_B;
@@ -237,8 +238,9 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
             cur_pat = pat;
         }
         const float* orow = a.logits + row * a.ldl;
-        const float* xrow = a.x + row * a.ldx;
-        const uint8_t* grow = a.goodloc + row * a.ldg;
+        const int64_t srow = a.ridx ? a.ridx[row] : row;
+        const float* xrow = a.x + srow * a.ldx;
+        const uint8_t* grow = a.goodloc + srow * a.ldg;
         const float sf = a.sizefactor[row];
         const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
         const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
@@ -363,9 +365,10 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     auto fetch = [&](int i, int64_t row) {
         const int64_t c = 4ll * (tid + NT * i);
         if (c < G) {
+            const int64_t srow = a.ridx ? a.ridx[row] : row;
             ev[i] = *reinterpret_cast<const f32x4*>(a.logits + row * a.ldl + c);
-            xv[i] = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + c);
-            mb[i] = *reinterpret_cast<const unsigned*>(a.goodloc + row * a.ldg + c);
+            xv[i] = *reinterpret_cast<const f32x4*>(a.x + srow * a.ldx + c);
+            mb[i] = *reinterpret_cast<const unsigned*>(a.goodloc + srow * a.ldg + c);
         } else {
             ev[i] = ninf; xv[i] = zero4; mb[i] = 0u;
         }
@@ -664,7 +667,8 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                                    const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
                                    const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
                                    void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
-                                   int32_t* status_dev, const float* lgx1_rowsum, void* stream) {
+                                   int32_t* status_dev, const float* lgx1_rowsum, const int64_t* row_index,
+                                   void* stream) {
     C2_CHECK(logits && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dtheta && ws && status_dev,
              "null pointer");
     C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
@@ -680,7 +684,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             lgx1_rowsum, ldl, ldx, ldg, lddl, B, G, C, inv_B};
+             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);

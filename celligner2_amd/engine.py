@@ -292,9 +292,9 @@ class StepEngine:
         classes [B,P] i64 or None.  Returns a fp32 [4] tensor (recon, kl, mmd, class_ce); leaves everything the
         backward needs in the workspace."""
         cfg = self.cfg
-        x = batch["x"]
+        x = batch.get("x")  # None: the rows live in the resident matrices (x_full / goodloc_full / row_index)
         cond = batch.get("batch")
-        B, G = x.shape
+        B, G = x.shape if x is not None else batch["xin"].shape
         Bn = B * self.world_size
         inv_B = 1.0 / Bn
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
@@ -305,13 +305,14 @@ class StepEngine:
         status.zero_()
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
-        if log_in or xt != F32:
+        pre = batch.get("xin")  # already produced by the device-resident gather
+        if pre is not None and pre.dtype == xt:
+            xin = pre
+        elif x is None:
+            raise ValueError("a batch without x needs xin in the encoder's operand dtype")
+        elif log_in or xt != F32:
             xin = self.buf("xin", (B, G), xt)
-            pre = batch.get("xin")  # already produced by the device-resident gather
-            if pre is not None and pre.dtype == xt:
-                xin = pre
-            else:
-                ops.prep_input(x, xin, log_in)
+            ops.prep_input(x, xin, log_in)
         else:
             xin = x
         self._xin = xin
@@ -347,10 +348,16 @@ class StepEngine:
         if cfg["recon_loss"] == "nb":
             C = cfg["n_conditions"]
             ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
-            ops.recon_nb(logits, x, batch["goodloc"], batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
+            if x is None:
+                xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
+            else:
+                xs, gl, ridx = x, batch["goodloc"], None
+            ops.recon_nb(logits, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
                          losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
-                         lgx1=batch.get("lgx1"))
+                         lgx1=batch.get("lgx1"), row_index=ridx)
         elif cfg["recon_loss"] == "mse":
+            if x is None:
+                raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")
             ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws)
         else:
             raise NotImplementedError("recon_loss='zinb' is not built yet (SURVEY.md 8(f) rank 3)")

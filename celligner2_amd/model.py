@@ -337,15 +337,27 @@ class Celligner2(nn.Module):
 
     # ------------------------------------------------------------------ the reference's API
     def forward(self, x=None, batch=None, sizefactor=None, classes=None, weight=None, goodloc=None,
-                main_dataset=None, xin=None, lgx1=None):
-        dev = x.device
-        B = x.shape[0]
-        x = x.float().contiguous()
-        if goodloc is None:
-            goodloc = torch.ones_like(x, dtype=torch.bool)
-        if sizefactor is None:
-            sizefactor = x.sum(1)
-        bt = dict(x=x, goodloc=goodloc.contiguous(), sizefactor=sizefactor.reshape(B).float().contiguous())
+                main_dataset=None, xin=None, lgx1=None, x_full=None, goodloc_full=None, row_index=None):
+        """The reference's forward (celligner2.py:259-374).  Extra keywords, all produced by DeviceDataset.gather:
+        xin (encoder input already transformed), lgx1 (data-only NB term), and x_full / goodloc_full / row_index
+        (the batch's counts are rows `row_index` of the resident matrices; x itself is then not needed)."""
+        if x is None:
+            if x_full is None or row_index is None or xin is None or sizefactor is None:
+                raise ValueError("forward needs x, or x_full + row_index + xin + sizefactor from a resident dataset")
+            dev = xin.device
+            B = xin.shape[0]
+            bt = dict(x=None, x_full=x_full, row_index=row_index,
+                      goodloc_full=goodloc_full if goodloc_full is not None else torch.ones_like(x_full, dtype=torch.bool),
+                      sizefactor=sizefactor.reshape(B).float().contiguous())
+        else:
+            dev = x.device
+            B = x.shape[0]
+            x = x.float().contiguous()
+            if goodloc is None:
+                goodloc = torch.ones_like(x, dtype=torch.bool)
+            if sizefactor is None:
+                sizefactor = x.sum(1)
+            bt = dict(x=x, goodloc=goodloc.contiguous(), sizefactor=sizefactor.reshape(B).float().contiguous())
         if batch is not None:
             bt["batch"] = batch.long().contiguous()
         elif self.n_conditions:

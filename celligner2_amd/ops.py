@@ -241,9 +241,14 @@ def nb_row_const(x, goodloc, out=None):
     return out
 
 
-def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status, lgx1=None):
+def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status, lgx1=None,
+             row_index=None):
+    """row_index: x / goodloc are the resident [N,G] matrices, batch row b = their row row_index[b]."""
     L.require_gpu(logits, x, goodloc, dlogits)
-    B, G = x.shape
+    B, G = logits.shape
+    assert x.shape[1] == G and goodloc.shape == x.shape and (row_index is not None or x.shape[0] == B)
+    if row_index is not None:
+        assert row_index.dtype == torch.int64 and row_index.is_contiguous() and row_index.numel() == B and row_index.is_cuda
     C = theta.shape[1]
     assert goodloc.dtype in (torch.bool, torch.uint8) and theta.is_contiguous() and cond.is_contiguous()
     assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
@@ -253,7 +258,8 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
     check(lib.c2_recon_nb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"), ptr(goodloc),
                                   _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta), ptr(cond), C, B, G,
                                   float(inv_B), ptr(loss_out), ptr(dlogits), dt_code(dlogits.dtype),
-                                  _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws), ptr(status), ptr(lgx1), stream()))
+                                  _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws), ptr(status), ptr(lgx1), ptr(row_index),
+                                  stream()))
 
 
 def recon_mse(logits, x, goodloc, inv_B, loss_out, dlogits, ws):
@@ -323,7 +329,7 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
     n = idx.numel()
     C = cond.shape[1] if cond is not None else 0
     P = classes.shape[1] if classes is not None else 0
-    assert X.is_contiguous() and x_out.is_contiguous() and idx.dtype == torch.int64
+    assert X.is_contiguous() and (x_out is None or x_out.is_contiguous()) and idx.dtype == torch.int64
     check(lib.c2_gather_rows(ptr(X), ptr(goodloc), ptr(sizefactor), ptr(cond), ptr(classes), G, C, P, ptr(idx), n,
                              ptr(x_out), ptr(goodloc_out), ptr(sf_out), ptr(cond_out), ptr(classes_out), ptr(xin_out),
                              dt_code(xin_out.dtype) if xin_out is not None else 0,

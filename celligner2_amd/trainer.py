@@ -151,7 +151,7 @@ class _Loader:
                     continue
                 sub = sub[self.world.rank * per:(self.world.rank + 1) * per]
             yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}),
-                                 self.nb_const)
+                                 self.nb_const, resident_rows=self.nb_const)
 
 
 class Trainer:

@@ -131,13 +131,16 @@ int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64_t slab_str
  * Adds recon to *loss_out; writes dlogits (dtype dl_dtype, unit upstream gradient) and dtheta [G,C].
  * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set non-zero if a cond value is outside [0,C).
  * lgx1_rowsum: NULL, or [B] with sum_g goodloc*lgamma(x+1) of each row (c2_nb_row_const): that term of
- * losses.py:60-64 depends on the data only, so a resident dataset evaluates it once instead of every step. */
+ * losses.py:60-64 depends on the data only, so a resident dataset evaluates it once instead of every step.
+ * row_index: NULL, or [B] int64: x and goodloc are then the RESIDENT matrices and row b of the batch is their row
+ * row_index[b] (logits, sizefactor, cond, lgx1_rowsum, dlogits stay batch-ordered): the loss reads the counts
+ * where they live instead of from a gathered copy. */
 size_t c2_recon_nb_ws(int64_t B, int64_t G, int C);
 int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
                         int64_t ldg, const float* sizefactor, const float* theta, const int64_t* cond, int C,
                         int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
                         int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
-                        void* stream);
+                        const int64_t* row_index, void* stream);
 
 /* out[b] = sum_g goodloc[b][g] * lgamma(x[b][g] + 1): the data-only term of the NB log-likelihood
  * (losses.py:60-64, `- torch.lgamma(x + 1)`), for c2_recon_nb_fwd_bwd's lgx1_rowsum. */
@@ -195,7 +198,8 @@ int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* Device-resident dataset -> batch (replaces AnnotatedDataset.__getitem__ + custom_collate + .to(device),
  * dataset/celligner2/anndata.py:89-105, trainers/celligner2/_utils.py:188-225, trainer.py:274-275):
  * rows idx[0..n) of x/goodloc/sizefactor/cond/classes are gathered into dense batch tensors; xin
- * (= log(1+x) or x, dtype xin_dtype) is produced in the same pass (may be NULL). */
+ * (= log(1+x) or x, dtype xin_dtype) is produced in the same pass (may be NULL).  x_out and goodloc_out may be
+ * NULL when the consumer reads the resident rows itself (c2_recon_nb_fwd_bwd's row_index). */
 int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
                    const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n, float* x_out,
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,

@@ -258,6 +258,18 @@ def test_recon_nb(B, G, C, multi, dl_dtype):
     assert abs(loss2.item() - recon64) < 1e-4 * abs(recon64)
     assert rel(dl2, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
     assert rel(dth2, dth64) < 1e-4
+    # same batch read through a row index from a larger "resident" matrix (rows permuted, padded with decoys)
+    perm = rng.permutation(B + 3)[:B]
+    xf = rng.poisson(3.0, (B + 3, G)).astype(np.float32)
+    gf = rng.uniform(size=(B + 3, G)) > 0.5
+    xf[perm], gf[perm] = x, good
+    loss3 = torch.zeros(1, device=DEV)
+    dl3 = torch.empty(B, G, device=DEV, dtype=dl_dtype)
+    dth3 = torch.empty(G, C, device=DEV)
+    ops.recon_nb(T(o), T(xf), T(gf), T(sf), T(theta), T(cond), 1.0 / B, loss3, dl3, dth3, ws, status, lgx1=lgx,
+                 row_index=T(perm.astype(np.int64)))
+    assert abs(loss3.item() - loss2.item()) <= 1e-6 * abs(recon64)
+    assert torch.equal(dl3, dl2) and torch.equal(dth3, dth2)
 
 
 def test_recon_nb_golden_wide_row():
@@ -411,6 +423,14 @@ def test_prep_and_gather():
     assert np.array_equal(so.cpu().numpy(), sf[idx]) and np.array_equal(co.cpu().numpy(), cond[idx])
     assert np.array_equal(po.cpu().numpy(), cls[idx])
     assert rel(xin, np.log(1 + X[idx].astype(np.float64))) < 1e-2
+    # resident-row form: no x / goodloc copies, xin only (fp32 here), vectorised and scalar store paths
+    for dt, g_cols in ((torch.float32, G), (torch.bfloat16, G), (torch.bfloat16, G - 1)):
+        Xs = np.ascontiguousarray(X[:, :g_cols])
+        xin2 = torch.full((21, g_cols), float("nan"), device=DEV, dtype=dt)
+        so2 = torch.empty(21, device=DEV)
+        ops.gather_rows(T(Xs), None, T(sf), T(cond), None, T(idx), None, None, so2, co, None, xin2, True)
+        assert rel(xin2, np.log(1 + Xs[idx].astype(np.float64))) < (1e-6 if dt == torch.float32 else 1e-2)
+        assert np.array_equal(so2.cpu().numpy(), sf[idx])
     out = torch.empty(N, G, device=DEV)
     ops.prep_input(T(X), out, True)
     assert rel(out, np.log(1 + X.astype(np.float64))) < 1e-6

@@ -85,7 +85,7 @@ def test_loader_shards_global_batches():
         def __len__(self):
             return 23
 
-        def gather(self, idx, *a):
+        def gather(self, idx, *a, **kw):
             return idx
 
     class W:
