@@ -28,6 +28,12 @@
 namespace c2 {
 namespace wide {
 
+// Ablation builds only (-DC2_GEMM_DBG=1: no DMA after nothing, 2: no MFMA, 3: neither); 0 in the product.
+#ifndef C2_GEMM_DBG
+#define C2_GEMM_DBG 0
+#endif
+constexpr int dbg = C2_GEMM_DBG;
+
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;  // tiles along M that share a panel of B
 
@@ -166,7 +172,7 @@ __device__ __forceinline__ void wait_loads(int c) {
 // T+D are in flight or landed.  D = 2 for the 256x256 tile (5 x 32 KB), D = 4 for the 128x128 tile (9 x 16 KB): its
 // K-step is short (16 MFMAs per wave), so the ~1 us LDS-DMA round trip needs more tiles ahead of it.
 template <bool A_RC, bool B_RC, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n, int dbg) {
+__global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int BX = 32 * NW;             // block tile edge: 256 or 128
     constexpr int D = NW == 8 ? 2 : 4;
     constexpr int NSLOT = 2 * D + 1;
@@ -402,7 +408,7 @@ int wide_tile(int dtype, const GemmArgs& a) {
 }
 
 template <int NW>
-static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream, int dbg) {
+static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
     using namespace wide;
     constexpr int BX = 32 * NW;
     constexpr int LDS = (NW == 8 ? 5 : 9) * BX * BK * 2;
@@ -416,17 +422,16 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
         attr_set = true;
     }
     if (layout == 0)
-        hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     else if (layout == 1)
-        hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n, dbg);
+        hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
 }
 
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {
-    static const int dbg = getenv("C2_GEMM_DBG") ? atoi(getenv("C2_GEMM_DBG")) : 0;
-    if (tile == 256) launch_nw<8>(layout, a, nslab, stream, dbg);
-    else launch_nw<4>(layout, a, nslab, stream, dbg);
+    if (tile == 256) launch_nw<8>(layout, a, nslab, stream);
+    else launch_nw<4>(layout, a, nslab, stream);
     return 0;
 }
 
