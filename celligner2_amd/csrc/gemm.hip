@@ -338,6 +338,17 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int
     }
 }
 
+__global__ void sum_slabs_2d_kernel(const float* __restrict__ slabs, int nslab, int64_t stride, int64_t rows, int64_t cols,
+                                    int64_t lds, float* __restrict__ out, int64_t ldo) {
+    const int64_t n = rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[k * stride + r * lds + c];
+        out[r * ldo + c] = s;
+    }
+}
+
 }  // namespace c2
 
 using namespace c2;
@@ -459,6 +470,17 @@ extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int6
         a.B_lo = (const bf16_t*)A + M * lda;
     }
     C2_CHECK(gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_stride, int64_t rows, int64_t cols, int64_t lds,
+                               float* out, int64_t ldo, void* stream) {
+    C2_CHECK(slabs && out && nslab >= 1 && rows >= 0 && cols >= 0 && lds >= cols && ldo >= cols, "bad arguments");
+    if (rows == 0 || cols == 0) return 0;
+    int blocks = (int)std::min<int64_t>((rows * cols + 255) / 256, 2048);
+    hipLaunchKernelGGL(sum_slabs_2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslab, slab_stride, rows,
+                       cols, lds, out, ldo);
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -238,6 +238,8 @@ class StepEngine:
         g = self.gbuf(name)
         N, K = g.shape
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
+        if not pl and self._wgrad_two_part(dy, a, g, alpha):
+            return
         ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3, planes=pl)
         if ns == 1:
             ops.linear_wgrad(dy2, a2, g, alpha=alpha, x3=self.x3)
@@ -245,6 +247,36 @@ class StepEngine:
             slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
             ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
+
+    def _wgrad_two_part(self, dy, a, g, alpha):
+        """A gene-width weight gradient whose 256x256 tiles number a little more than a multiple of the 256 CUs
+        (19000 x 1024: 300 tiles = two rounds, the second 17 % full) runs as two launches: the tiles of the full
+        rounds unsplit, the remaining strip with its batch reduction split into slabs so that it is one short round."""
+        N, K = g.shape
+        M = dy.shape[0]
+        if ops.gemm_tile(dy.dtype, N, K, M, self.x3) != 256:
+            return False
+        tm, tn = (N + 255) // 256, (K + 255) // 256
+        full, rem = divmod(tm * tn, 256)
+        per = min(tm, tn)
+        if full < 1 or rem == 0 or rem > 96 or (full * 256) % per or M < 1024:
+            return False
+        cut = (full * 256 // per) * 256  # rows (tm >= tn) or columns of the output covered by the full rounds
+        by_rows = tm >= tn
+        rest = (N if by_rows else K) - cut
+        tiles2 = ((rest + 255) // 256) * per
+        ns = max(1, min(16, 256 // tiles2, M // 256))
+        if by_rows:
+            ops.linear_wgrad(dy[:, :cut], a, g[:cut], alpha=alpha)
+            slabs = self.buf(f"wgrad.strip.{ns}x{rest}x{K}", (ns, rest, K))
+            ops.linear_wgrad(dy[:, cut:], a, slabs, nslab=ns, alpha=alpha)
+            ops.sum_slabs(slabs, g[cut:])
+        else:
+            ops.linear_wgrad(dy, a[:, :cut], g[:, :cut], alpha=alpha)
+            slabs = self.buf(f"wgrad.strip.{ns}x{N}x{rest}", (ns, N, rest))
+            ops.linear_wgrad(dy, a[:, cut:], slabs, nslab=ns, alpha=alpha)
+            ops.sum_slabs_2d(slabs, g[:, cut:])
+        return True
 
     def _block_fwd(self, blk, a, cond, masks, train, save):
         B = a.shape[0]

@@ -153,6 +153,14 @@ def sum_slabs(slabs, out):
     return out
 
 
+def sum_slabs_2d(slabs, out):
+    """out[r, c] = sum_s slabs[s, r, c] for a strided 2-D `out` (a block of a wider matrix)."""
+    S, rows, cols = slabs.shape
+    assert slabs.is_contiguous() and tuple(out.shape) == (rows, cols) and out.stride(1) == 1
+    check(lib.c2_sum_slabs_2d(ptr(slabs), S, rows * cols, rows, cols, cols, ptr(out), out.stride(0), stream()))
+    return out
+
+
 def _slabs(y):
     """(ptr-tensor, ld, nslab, slab_stride, rows, cols) of a [M,N] or [S,M,N] fp32 tensor."""
     if y.dim() == 3:

@@ -81,6 +81,9 @@ int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void
 
 /* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
 int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);
+/* The same for a [rows, cols] block of a wider matrix: out[r*ldo + c] = sum_s slabs[s*slab_stride + r*lds + c]. */
+int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_stride, int64_t rows, int64_t cols, int64_t lds,
+                    float* out, int64_t ldo, void* stream);
 
 /* Tail of one layer block (modules.py:77-107,124-130 cond add; :298-312 norm/act/dropout):
  *   h = sum_s Y[s] (+ bias) (+ sum_j cond[b][j] * Wc[:,j]);  LayerNorm(no affine, eps 1e-5, biased var)

@@ -505,3 +505,26 @@ def test_linear_bf16_planes(M, N, K):
         dws = torch.full((4, N, K), float("nan"), device=DEV)
         ops.linear_wgrad(pdy, pa, dws, nslab=4)
         assert relt(dws.sum(0), dy64.T @ a64) < 5e-5
+
+
+@pytest.mark.parametrize("by_rows", [True, False])
+def test_wgrad_two_part_schedule(by_rows):
+    """engine.StepEngine._wgrad_two_part: full rounds of 256x256 tiles unsplit + the remaining strip as slabs, along
+    the rows or the columns of the weight gradient (strided views of dY / A / dW), against an fp64 product."""
+    from celligner2_amd.engine import StepEngine
+    ops = _ops()
+    eng = StepEngine.__new__(StepEngine)
+    eng.x3, eng._ws, eng.dev = False, {}, torch.device(DEV)
+    M, big, small = 1024, 66 * 256 + 40, 1024
+    N, K = (big, small) if by_rows else (small, big)
+    g = torch.Generator(device="cpu").manual_seed(7 + by_rows)
+    dy = torch.randn(M, N, generator=g).to(DEV).bfloat16()
+    a = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    dw = torch.full((N, K), float("nan"), device=DEV)
+    alpha = torch.tensor([0.25], device=DEV)
+    assert eng._wgrad_two_part(dy, a, dw, alpha)
+    want = 0.25 * dy.double().T @ a.double()
+    assert float((dw.double() - want).abs().max() / want.abs().max()) < 2e-5
+    # shapes that fill whole rounds (or are too small) are left to the ordinary path
+    assert not eng._wgrad_two_part(dy[:, :256 * 4] if by_rows else dy, a if by_rows else a[:, :256 * 4],
+                                   torch.empty((256 * 4, K) if by_rows else (N, 256 * 4), device=DEV), None)
