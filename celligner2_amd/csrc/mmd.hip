@@ -159,8 +159,10 @@ constexpr int DC = 64;      // feature chunk staged in LDS
 constexpr int LDT = DC + 1; // LDS row stride of a feature tile
 
 // one wave per block; block (it, js, dchunk)
-template <typename TF>
-__global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, int64_t ldf,
+// FAST: fp32 features, 16-byte aligned rows, D <= 64 (the latent z): one feature chunk, vector loads only, the next
+// column tile prefetched into registers.  The general instance keeps every path (bf16 / ragged / chunked D).
+template <typename TF, bool FAST>
+__global__ __launch_bounds__(64, FAST ? 3 : 1) void mmd_tile_kernel(const TF* __restrict__ f, int64_t ldf,
                                                       const int32_t* __restrict__ part_id,
                                                       const float* __restrict__ wt, const float* __restrict__ norms,
                                                       int64_t row0, int64_t Bl, int64_t Bg, int D, int jt_per,
@@ -173,27 +175,25 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
     const int it = blockIdx.x, js = blockIdx.y, dchunk = blockIdx.z;
     const int64_t i0 = (int64_t)it * TS;  // local row index of the tile
     const int hi = lane >> 5, lo = lane & 31;
-    const int nchunks = (D + DC - 1) / DC;
-    const int dgrad0 = dchunk * DC;  // gradient columns owned by this block
+    const int nchunks = FAST ? 1 : (D + DC - 1) / DC;
+    const int dgrad0 = FAST ? 0 : dchunk * DC;  // gradient columns owned by this block
 
     // per-lane row metadata (16 rows) and its norms/parts
     float ni[16];
     int pi[16];
-    int64_t gi[16];
+    const int64_t gi0 = row0 + i0 + 4 * hi;  // global row of accumulator element e: gi0 + (e & 3) + 8 * (e >> 2)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
         const int64_t li = i0 + r;
-        gi[e] = row0 + li;
         const bool ok = li < Bl;
-        ni[e] = ok ? norms[gi[e]] : 0.f;
-        pi[e] = ok ? part_id[gi[e]] : -1;
+        ni[e] = ok ? norms[row0 + li] : 0.f;
+        pi[e] = ok ? part_id[row0 + li] : -1;
     }
-    const bool vec_ok = (sizeof(TF) == 4) && ((ldf & 3) == 0) && ((D & 3) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(f) & 15) == 0);
-    auto stage = [&](float* dst, int64_t grow0, int64_t nrows_total, int d0) {
-        // 32 rows x 64 cols: 16 lanes per row, 4 consecutive features each (one 16-byte load when aligned)
-        f32x4 v[8];
+    const bool vec_ok = FAST || ((sizeof(TF) == 4) && ((ldf & 3) == 0) && ((D & 3) == 0) &&
+                                 ((reinterpret_cast<uintptr_t>(f) & 15) == 0));
+    // 32 rows x 64 cols: 16 lanes per row, 4 consecutive features each (one 16-byte load when aligned)
+    auto stage_load = [&](f32x4 (&v)[8], int64_t grow0, int64_t nrows_total, int d0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int idx = lane + 64 * k;  // 0..511
@@ -202,15 +202,17 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
             const int d = d0 + c4;
             v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (gr < nrows_total && d < D) {
-                if (vec_ok) {
+                if (FAST || vec_ok) {
                     v[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(f) + gr * ldf + d);
-                } else {
+                } else if (!FAST) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (d + q < D) v[k][q] = ld_as_f32<TF>(f + gr * ldf + d + q);
                 }
             }
         }
+    };
+    auto stage_store = [&](float* dst, const f32x4 (&v)[8]) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int idx = lane + 64 * k;
@@ -218,6 +220,11 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[r * LDT + c4 + q] = v[k][q];
         }
+    };
+    auto stage = [&](float* dst, int64_t grow0, int64_t nrows_total, int d0) {
+        f32x4 v[8];
+        stage_load(v, grow0, nrows_total, d0);
+        stage_store(dst, v);
     };
 
     f32x16 gacc[2];
@@ -228,8 +235,11 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
 
     const int64_t njt = (Bg + TS - 1) / TS;
     const int64_t jt_beg = (int64_t)js * jt_per, jt_end = min(njt, jt_beg + jt_per);
+    // single feature chunk (D <= 64): the next column tile is fetched into registers while this one is evaluated
+    f32x4 vnext[8];
     if (nchunks == 1) {
         stage(ldsI, row0 + i0, row0 + Bl, 0);
+        if (jt_beg < jt_end) stage_load(vnext, jt_beg * TS, Bg, 0);
     }
     for (int64_t jt = jt_beg; jt < jt_end; ++jt) {
         const int64_t j0 = jt * TS;
@@ -239,8 +249,13 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         for (int ch = 0; ch < nchunks; ++ch) {
             __syncthreads();
-            if (nchunks > 1) stage(ldsI, row0 + i0, row0 + Bl, ch * DC);
-            stage(ldsJ, j0, Bg, ch * DC);
+            if (nchunks > 1) {
+                stage(ldsI, row0 + i0, row0 + Bl, ch * DC);
+                stage(ldsJ, j0, Bg, ch * DC);
+            } else {
+                stage_store(ldsJ, vnext);
+                if (jt + 1 < jt_end) stage_load(vnext, (jt + 1) * TS, Bg, 0);
+            }
             __syncthreads();
 #pragma unroll 8
             for (int s = 0; s < DC / 2; ++s) {
@@ -258,9 +273,10 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float w = 0.f;
-            if (jok && pi[e] >= 0) w = wt[pi[e] * MAXP + pj];
+            if (jok && pi[e] >= 0) w = wt[(unsigned)(pi[e] * MAXP + pj)];
             float d = fmaxf(ni[e] + nj - 2.f * acc[e], 0.f);
-            if (gi[e] == gj) d = 0.f;  // exact self distance
+            const bool self = (gi0 + ((e & 3) + 8 * (e >> 2))) == gj;
+            if (self) d = 0.f;  // exact self distance
             float S = 0.f, Wp = 0.f;
             if (w != 0.f) {
                 // beta_k = 1/(2 alpha_k) folded at compile time in fp32, as the reference forms it (losses.py:156);
@@ -282,8 +298,10 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const TF* __restrict__ f, 
             lacc += w * S;
             // a self pair adds K = 19 to the loss but no gradient (f_i - f_i = 0): drop its 1e6-scale weight,
             // which would otherwise only cancel to fp32 rounding in G_i - r_i f_i
-            gw[e] = (gi[e] == gj) ? 0.f : w * Wp;
+            gw[e] = self ? 0.f : w * Wp;
             racc[e] += gw[e];
+            // keep the scheduler from interleaving all 16 x 19 exponentials (it did: 437 registers, one wave per SIMD)
+            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- gradient contraction  G_i += sum_j gw_ij f_j  (columns dgrad0 .. dgrad0+63)
         __syncthreads();
@@ -382,13 +400,18 @@ extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const 
     if (f_dtype == C2_BF16) {
         hipLaunchKernelGGL((row_norms_kernel<bf16_t>), dim3((unsigned)((Bg + 3) / 4)), dim3(256), 0, st, (const bf16_t*)feat,
                            ldf, Bg, (int)D, norms);
-        hipLaunchKernelGGL((mmd_tile_kernel<bf16_t>), grid, dim3(64), 0, st, (const bf16_t*)feat, ldf, part_id, wt, norms,
-                           row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
+        hipLaunchKernelGGL((mmd_tile_kernel<bf16_t, false>), grid, dim3(64), 0, st, (const bf16_t*)feat, ldf, part_id, wt,
+                           norms, row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
     } else {
         hipLaunchKernelGGL((row_norms_kernel<float>), dim3((unsigned)((Bg + 3) / 4)), dim3(256), 0, st, (const float*)feat,
                            ldf, Bg, (int)D, norms);
-        hipLaunchKernelGGL((mmd_tile_kernel<float>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt, norms, row0,
-                           Bl, Bg, (int)D, jt_per, beta, partials, slabs);
+        const bool fast = D <= DC && (D & 3) == 0 && (ldf & 3) == 0 && aligned16(feat);
+        if (fast)
+            hipLaunchKernelGGL((mmd_tile_kernel<float, true>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt,
+                               norms, row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
+        else
+            hipLaunchKernelGGL((mmd_tile_kernel<float, false>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt,
+                               norms, row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
     }
     c2_sum_slabs(slabs, jsplit, Bl * D, dfeat, Bl * D, stream);
     launch_finalize_sum(partials, nit * jsplit, loss_out, st);
