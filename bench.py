@@ -180,6 +180,12 @@ def main():
         n_launch = max(len(prof), 1)
         peak = 2500.0 if args.precision == "bf16" else 157.3
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # HBM bytes per GEMM launch: measured in separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+        # profiles/r01_gemm_pmc.json); only valid for the configuration it was measured on
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        if args.config == "c4" and args.precision == "bf16" and B == CONFIGS["c4"]["B"] and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         out = {
             "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes",
             "value": cells / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,8 +195,8 @@ def main():
                                    f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "kernel": "gemm_kernel (gene-width Linear fwd/dgrad/wgrad)",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "c2::wide::gemm_wide_kernel<*,*,8> (gene-width Linear fwd/dgrad/wgrad)",
                          "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
                          "gemm_ms_per_step": gemm_ms / args.steps},
         }
