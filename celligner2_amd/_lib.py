@@ -39,8 +39,8 @@ _SIGS = {
     "c2_split_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs_2d": (i32, [vp, i32, i64, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
-    "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp]),
-    "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp]),
+    "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp, vp]),
+    "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp, vp]),
     "c2_bias_cond_grad_ws": (sz, [i64, i64, i32]),
     "c2_bias_cond_grad": (i32, [vp, i32, i64, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp]),
     "c2_reduce_ws": (sz, []),

@@ -217,6 +217,163 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Vector forms of the two layer-tail kernels (H % 4 == 0, 16-byte aligned rows, H <= 256 * EPL): every access is a
+// 16-byte load/store (8 bytes for bf16 outputs, 4 for the mask), the row lives in registers between the passes.
+// `planes` (optional, with fp32 output): the same values as two bf16 planes [2][B][H] (hi, lo = x - hi), the
+// operand form of the narrow bf16x3 GEMMs (C2_BF16X3P), written here instead of by a separate split pass.
+__device__ __forceinline__ void store_out4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store_out4(bf16_t* p, const f32x4& v) {
+    u32x2 pk;
+    pk[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    pk[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<u32x2*>(p) = pk;
+}
+__device__ __forceinline__ void store_planes4(bf16_t* hi_p, int64_t plane, const f32x4& v) {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f2bf(v[e]);
+        l[e] = f2bf(v[e] - bf2f(h[e]));
+    }
+    u32x2 ph, pl;
+    ph[0] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    ph[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+    pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+    *reinterpret_cast<u32x2*>(hi_p) = ph;
+    *reinterpret_cast<u32x2*>(hi_p + plane) = pl;
+}
+
+template <typename TO, int EPL>
+__global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
+    const float* __restrict__ Y, int64_t ldy, int nslab, int64_t slab_stride, const float* __restrict__ bias,
+    const int64_t* __restrict__ cond, int C, const float* __restrict__ Wc, int64_t ldwc,
+    const uint8_t* __restrict__ mask, float keep_scale, int use_ln, int64_t B, int H, TO* __restrict__ act,
+    int64_t ldact, float* __restrict__ yhat, float* __restrict__ rstd_out, bf16_t* __restrict__ planes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int64_t* crow = cond ? cond + row * C : nullptr;
+    f32x4 cache[EPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        if (c < H) {
+            for (int s = 0; s < nslab; ++s) h += *reinterpret_cast<const f32x4*>(Y + s * slab_stride + row * ldy + c);
+            if (bias) h += *reinterpret_cast<const f32x4*>(bias + c);
+            if (crow) {
+                for (int j = 0; j < C; ++j) {
+                    const float cj = (float)crow[j];
+                    if (cj != 0.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] += cj * Wc[(int64_t)(c + e) * ldwc + j];
+                    }
+                }
+            }
+        }
+        cache[i] = h;
+        sum += (h[0] + h[1]) + (h[2] + h[3]);
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (use_ln) {
+        mean = wave_sum(sum) / (float)H;
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < H) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = cache[i][e] - mean;
+                    vs += d * d;
+                }
+            }
+        }
+        const float var = wave_sum(vs) / (float)H;
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+    }
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+    const int64_t plane = B * (int64_t)H;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < H) {
+            f32x4 yh, r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yh[e] = (cache[i][e] - mean) * rstd;
+                r[e] = fmaxf(yh[e], 0.f);
+            }
+            if (yhat) *reinterpret_cast<f32x4*>(yhat + row * (int64_t)H + c) = yh;
+            if (mask) {
+                const unsigned mb = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = ((mb >> (8 * e)) & 0xffu) ? r[e] * keep_scale : 0.f;
+            }
+            store_out4(act + row * ldact + c, r);
+            if (planes) store_planes4(planes + row * (int64_t)H + c, plane, r);
+        }
+    }
+}
+
+template <typename TO, int EPL>
+__global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
+    const float* __restrict__ dA, int64_t ldda, int nslab, int64_t slab_stride, const float* __restrict__ extra,
+    int64_t ldextra, const float* __restrict__ extra_scale_dev, const uint8_t* __restrict__ mask, float keep_scale,
+    int use_ln, const float* __restrict__ yhat, const float* __restrict__ rstd_in, int64_t B, int H,
+    TO* __restrict__ dh, int64_t lddh, bf16_t* __restrict__ planes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float es = (extra && extra_scale_dev) ? *extra_scale_dev : 1.f;
+    f32x4 cdy[EPL], cyh[EPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, yh = d;
+        if (c < H) {
+            for (int s = 0; s < nslab; ++s) d += *reinterpret_cast<const f32x4*>(dA + s * slab_stride + row * ldda + c);
+            if (extra) d += es * *reinterpret_cast<const f32x4*>(extra + row * ldextra + c);
+            if (mask) {
+                const unsigned mb = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = ((mb >> (8 * e)) & 0xffu) ? d[e] * keep_scale : 0.f;
+            }
+            yh = *reinterpret_cast<const f32x4*>(yhat + row * (int64_t)H + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d[e] = yh[e] > 0.f ? d[e] : 0.f;
+                s1 += d[e];
+                s2 += d[e] * yh[e];
+            }
+        }
+        cdy[i] = d;
+        cyh[i] = yh;
+    }
+    float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+    if (use_ln) {
+        m1 = wave_sum(s1) / (float)H;
+        m2 = wave_sum(s2) / (float)H;
+        rstd = rstd_in[row];
+    }
+    const int64_t plane = B * (int64_t)H;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < H) {
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = use_ln ? (cdy[i][e] - m1 - cyh[i][e] * m2) * rstd : cdy[i][e];
+            store_out4(dh + row * lddh + c, g);
+            if (planes) store_planes4(planes + row * (int64_t)H + c, plane, g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // db / dWc: stage 1 -- block = 128 columns x RB rows: thread (cx, ry) sums 2 adjacent columns over every 8th row of
 // the chunk in ONE pass (bias and up to 8 condition columns together), the 8 row groups are combined through LDS;
 // stage 2 -- sum over row chunks (independent loads, unrolled).
@@ -511,8 +668,9 @@ extern "C" int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t
 extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                                const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
                                float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype,
-                               int64_t ldact, float* yhat, float* rstd, void* stream) {
+                               int64_t ldact, float* yhat, float* rstd, void* act_planes, void* stream) {
     C2_CHECK(Y && act, "null pointer");
+    C2_CHECK(!act_planes || act_dtype == C2_F32, "planes accompany an fp32 activation");
     C2_CHECK(act_dtype == C2_F32 || act_dtype == C2_BF16, "bad dtype");
     C2_CHECK(nslab >= 1 && ldy >= H && ldact >= H && H < (1ll << 31), "bad shape");
     C2_CHECK(!(cond && C > 0) || Wc, "cond given without Wc");
@@ -522,6 +680,25 @@ extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t s
     const float ks = 1.0f / (1.0f - p_drop);
     dim3 grid((unsigned)((B + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
+    const bool vec = (H % 4 == 0) && H <= 1024 && (ldy % 4 == 0) && (slab_stride % 4 == 0) && (ldact % 4 == 0) &&
+                     aligned16(Y) && (!bias || aligned16(bias)) && (!yhat || aligned16(yhat)) &&
+                     ((reinterpret_cast<uintptr_t>(act) & (act_dtype == C2_F32 ? 15 : 7)) == 0) &&
+                     (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
+                     (!act_planes || ((reinterpret_cast<uintptr_t>(act_planes) & 7) == 0 && (B * H) % 4 == 0));
+    C2_CHECK(vec || !act_planes, "act_planes needs the vector path (H % 4 == 0, H <= 1024, aligned rows)");
+#define LAUNCHV(TO, E)                                                                                                 \
+    hipLaunchKernelGGL((epilogue_fwd_vec_kernel<TO, E>), grid, dim3(256), 0, st, Y, ldy, nslab, slab_stride, bias, cond, \
+                       C, Wc, ldwc, mask, ks, use_ln, B, (int)H, (TO*)act, ldact, yhat, rstd, (bf16_t*)act_planes)
+    if (vec) {
+        if (act_dtype == C2_F32) {
+            if (H <= 256) LAUNCHV(float, 1); else if (H <= 512) LAUNCHV(float, 2); else LAUNCHV(float, 4);
+        } else {
+            if (H <= 256) LAUNCHV(bf16_t, 1); else if (H <= 512) LAUNCHV(bf16_t, 2); else LAUNCHV(bf16_t, 4);
+        }
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
+#undef LAUNCHV
 #define LAUNCH(TO, E)                                                                                              \
     hipLaunchKernelGGL((epilogue_fwd_kernel<TO, E>), grid, dim3(256), 0, st, Y, ldy, nslab, slab_stride, bias, cond, \
                        C, Wc, ldwc, mask, ks, use_ln, B, (int)H, (TO*)act, ldact, yhat, rstd)
@@ -538,8 +715,9 @@ extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t s
 extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
                                int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
                                int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
-                               int dh_dtype, int64_t lddh, void* stream) {
+                               int dh_dtype, int64_t lddh, void* dh_planes, void* stream) {
     C2_CHECK(dA && yhat && dh, "null pointer");
+    C2_CHECK(!dh_planes || dh_dtype == C2_F32, "planes accompany an fp32 gradient");
     C2_CHECK(!use_ln || rstd, "rstd needed with use_ln");
     C2_CHECK(dh_dtype == C2_F32 || dh_dtype == C2_BF16, "bad dtype");
     C2_CHECK(nslab >= 1 && ldda >= H && lddh >= H && H < (1ll << 31), "bad shape");
@@ -548,6 +726,26 @@ extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t
     const float ks = 1.0f / (1.0f - p_drop);
     dim3 grid((unsigned)((B + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
+    const bool vec = (H % 4 == 0) && H <= 1024 && (ldda % 4 == 0) && (slab_stride % 4 == 0) && (lddh % 4 == 0) &&
+                     aligned16(dA) && aligned16(yhat) && (!extra || (aligned16(extra) && ldextra % 4 == 0)) &&
+                     ((reinterpret_cast<uintptr_t>(dh) & (dh_dtype == C2_F32 ? 15 : 7)) == 0) &&
+                     (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
+                     (!dh_planes || ((reinterpret_cast<uintptr_t>(dh_planes) & 7) == 0 && (B * H) % 4 == 0));
+    C2_CHECK(vec || !dh_planes, "dh_planes needs the vector path (H % 4 == 0, H <= 1024, aligned rows)");
+#define LAUNCHV(TO, E)                                                                                               \
+    hipLaunchKernelGGL((epilogue_bwd_vec_kernel<TO, E>), grid, dim3(256), 0, st, dA, ldda, nslab, slab_stride, extra, \
+                       ldextra, extra_scale_dev, mask, ks, use_ln, yhat, rstd, B, (int)H, (TO*)dh, lddh,            \
+                       (bf16_t*)dh_planes)
+    if (vec) {
+        if (dh_dtype == C2_F32) {
+            if (H <= 256) LAUNCHV(float, 1); else if (H <= 512) LAUNCHV(float, 2); else LAUNCHV(float, 4);
+        } else {
+            if (H <= 256) LAUNCHV(bf16_t, 1); else if (H <= 512) LAUNCHV(bf16_t, 2); else LAUNCHV(bf16_t, 4);
+        }
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
+#undef LAUNCHV
 #define LAUNCH(TO, E)                                                                                            \
     hipLaunchKernelGGL((epilogue_bwd_kernel<TO, E>), grid, dim3(256), 0, st, dA, ldda, nslab, slab_stride, extra, \
                        ldextra, extra_scale_dev, mask, ks, use_ln, yhat, rstd, B, (int)H, (TO*)dh, lddh)

@@ -187,6 +187,16 @@ class StepEngine:
             self._aplanes[key] = pl
         return pl
 
+    def _tail_planes(self, key, t):
+        """bf16x3 mode: planes buffer that the layer-tail kernel fills together with its fp32 output `t` (registered
+        as t's planes for this step), or None when t is not an fp32 operand of a narrow GEMM / shape not vectorisable."""
+        B, H = t.shape
+        if not (self.x3 and t.dtype == F32 and t.is_contiguous() and H % 8 == 0 and H <= 1024 and (B * H) % 4 == 0):
+            return None
+        pl = self.buf(key, (2, B, H), torch.bfloat16)
+        self._aplanes[(t.data_ptr(), (B, H))] = pl
+        return pl
+
     def _wplanes_of(self, name):
         p = self.p[name]
         c = self._wplanes.get(name)
@@ -287,9 +297,10 @@ class StepEngine:
         rstd = self.buf(blk.name + ".rstd", (B,)) if save else None
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if (train and p > 0) else None
+        planes = self._tail_planes(blk.name + ".act.pl", act)
         ops.epilogue_fwd(y, self.p[blk.b].detach() if blk.b else None, cond if blk.use_cond else None,
                          self.p[blk.wc].detach() if blk.wc else None, mask, p if mask is not None else 0.0,
-                         self.cfg["use_ln"], act, yhat, rstd)
+                         self.cfg["use_ln"], act, yhat, rstd, planes=planes)
         return act
 
     def _block_bwd(self, blk, dact, a_in, cond, masks, need_da, out_slabs=None, extra=None, extra_scale=None):
@@ -299,8 +310,9 @@ class StepEngine:
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if p > 0 else None
         dh = self.buf(blk.name + ".dh", (B, H), blk.gt)
+        planes = self._tail_planes(blk.name + ".dh.pl", dh)
         ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"], self._ws[blk.name + ".yhat"],
-                         self._ws[blk.name + ".rstd"], dh, extra=extra, extra_scale=extra_scale)
+                         self._ws[blk.name + ".rstd"], dh, extra=extra, extra_scale=extra_scale, planes=planes)
         if self.p[blk.w].requires_grad:
             self._wgrad(dh, a_in, blk.w)
         need_b = blk.b is not None and self.p[blk.b].requires_grad

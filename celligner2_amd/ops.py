@@ -168,7 +168,14 @@ def _slabs(y):
     return y, y.stride(0), 1, 0, y.shape[0], y.shape[1]
 
 
-def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=None):
+def _planes_arg(planes, B, H):
+    if planes is None:
+        return None
+    assert planes.dtype == torch.bfloat16 and tuple(planes.shape) == (2, B, H) and planes.is_contiguous()
+    return ptr(planes)
+
+
+def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=None, planes=None):
     L.require_gpu(y, act)
     yt, ldy, ns, ss, B, H = _slabs(y)
     assert y.dtype == torch.float32 and tuple(act.shape) == (B, H)
@@ -183,11 +190,12 @@ def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=N
         assert yhat.is_contiguous() and tuple(yhat.shape) == (B, H) and yhat.dtype == torch.float32
     check(lib.c2_epilogue_fwd(ptr(yt), ldy, ns, ss, ptr(bias), ptr(cond) if C else None, C, ptr(wc) if C else None,
                               wc.stride(0) if C else 0, ptr(mask), float(p_drop), int(use_ln), B, H, ptr(act),
-                              dt_code(act.dtype), _row_major(act, "act"), ptr(yhat), ptr(rstd), stream()))
+                              dt_code(act.dtype), _row_major(act, "act"), ptr(yhat), ptr(rstd),
+                              _planes_arg(planes, B, H), stream()))
     return act
 
 
-def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_scale=None):
+def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_scale=None, planes=None):
     L.require_gpu(da, dh)
     dt, ldda, ns, ss, B, H = _slabs(da)
     assert da.dtype == torch.float32 and tuple(dh.shape) == (B, H) and yhat.is_contiguous()
@@ -195,7 +203,7 @@ def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_sca
         assert extra.dtype == torch.float32 and tuple(extra.shape) == (B, H)
     check(lib.c2_epilogue_bwd(ptr(dt), ldda, ns, ss, ptr(extra), extra.stride(0) if extra is not None else 0,
                               ptr(extra_scale), ptr(mask), float(p_drop), int(use_ln), ptr(yhat), ptr(rstd), B, H,
-                              ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), stream()))
+                              ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), _planes_arg(planes, B, H), stream()))
     return dh
 
 

@@ -89,18 +89,20 @@ int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_stride, int64_t 
  *   h = sum_s Y[s] (+ bias) (+ sum_j cond[b][j] * Wc[:,j]);  LayerNorm(no affine, eps 1e-5, biased var)
  *   when use_ln; ReLU; dropout (keep-mask u8, scale 1/(1-p)) when mask != NULL.
  * Writes act (dtype act_dtype) and, for the backward, yhat (fp32, normalised pre-activation) and
- * rstd (fp32 [B]).  cond is the int64 multi-hot matrix [B,C] (row stride C). */
+ * rstd (fp32 [B]).  cond is the int64 multi-hot matrix [B,C] (row stride C).
+ * act_planes: NULL, or (fp32 act only) [2][B][H] bf16: the activation again as hi / lo planes, the operand form
+ * of C2_BF16X3P GEMMs (saves a c2_split_bf16 pass); needs H % 4 == 0, H <= 1024 and 16-byte aligned rows. */
 int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                     const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
                     float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype, int64_t ldact,
-                    float* yhat, float* rstd, void* stream);
+                    float* yhat, float* rstd, void* act_planes, void* stream);
 
 /* Backward of the same tail:  dact = sum_s dA[s] (+ extra_scale * extra); through dropout, ReLU, LayerNorm.
- * Writes dh (dtype dh_dtype), the gradient w.r.t. the Linear output. */
+ * Writes dh (dtype dh_dtype), the gradient w.r.t. the Linear output; dh_planes as act_planes above. */
 int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
                     int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
                     int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
-                    int dh_dtype, int64_t lddh, void* stream);
+                    int dh_dtype, int64_t lddh, void* dh_planes, void* stream);
 
 /* Bias / condition-weight gradients of a block (autograd of modules.py:100-106):
  *   db[h] = alpha * sum_b dh[b][h];   dWc[h][j] = alpha * sum_b dh[b][h] * cond[b][j]

@@ -114,7 +114,8 @@ def test_linear_unaligned_views():
     assert rel(y, a.cpu().double().numpy() @ w.cpu().double().numpy().T) < 1e-5
 
 
-@pytest.mark.parametrize("H,C,p,use_ln", [(64, 3, 0.0, 1), (1024, 2, 0.1, 1), (1500, 0, 0.05, 1), (96, 4, 0.0, 0)])
+@pytest.mark.parametrize("H,C,p,use_ln", [(64, 3, 0.0, 1), (1024, 2, 0.1, 1), (1500, 0, 0.05, 1), (96, 4, 0.0, 0),
+                                          (512, 3, 0.05, 1), (30, 2, 0.0, 1)])
 @pytest.mark.parametrize("act_dtype", [torch.float32, torch.bfloat16])
 def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
     ops = _ops()
@@ -137,8 +138,12 @@ def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
     act = torch.empty(B, H, device=DEV, dtype=act_dtype)
     yhat = torch.empty(B, H, device=DEV)
     rstd = torch.empty(B, device=DEV)
+    want_pl = act_dtype == torch.float32 and H % 4 == 0 and H <= 1024 and (B * H) % 4 == 0
+    pl = torch.zeros(2, B, H, device=DEV, dtype=torch.bfloat16) if want_pl else None
     ops.epilogue_fwd(T(y), T(bias), T(cond[:, :C]) if C else None, T(wc[:, :C].copy()) if C else None,
-                     T(mask) if mask is not None else None, p, use_ln, act, yhat, rstd)
+                     T(mask) if mask is not None else None, p, use_ln, act, yhat, rstd, planes=pl)
+    if want_pl:  # the planes are the split of the fp32 activation, bit for bit
+        assert torch.equal(pl, ops.split_bf16(act))
     tol = 1e-4 if act_dtype == torch.float32 else 1e-2
     assert rel(act, out64) < tol
     assert rel(yhat, cache[2]) < 1e-4
@@ -150,8 +155,11 @@ def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
     d = dtot * (mk / (1 - p) if mk is not None else 1.0) * (yh > 0)
     dh64 = (d - d.mean(1, keepdims=True) - yh * (d * yh).mean(1, keepdims=True)) * rs if use_ln else d
     dh = torch.empty(B, H, device=DEV, dtype=act_dtype)
+    pl2 = torch.zeros(2, B, H, device=DEV, dtype=torch.bfloat16) if want_pl else None
     ops.epilogue_bwd(T(dout), T(mask) if mask is not None else None, p, use_ln, yhat, rstd, dh, extra=T(extra),
-                     extra_scale=T(np.array([0.25], np.float32)))
+                     extra_scale=T(np.array([0.25], np.float32)), planes=pl2)
+    if want_pl:
+        assert torch.equal(pl2, ops.split_bf16(dh))
     assert rel(dh, dh64) < (2e-4 if act_dtype == torch.float32 else 1e-2)
     # bias / cond grads from the kernel's own dh
     dh_np = dh.float().cpu().numpy().astype(np.float64)
