@@ -535,6 +535,126 @@ __global__ __launch_bounds__(256) void nb_row_const_kernel(const float* __restri
 
 constexpr int kNbMaxGroups = 512;
 
+// ---- ZINB (celligner2.py:286-296, losses.py:68-124): the NB kernel's row walk with a second logit matrix pi (dropout
+// head) and its gradient.  x < eps: ll = softplus(ptl) - softplus(-pi), ptl = -pi + theta (log(theta+eps) -
+// log(theta+mu+eps));  x > eps: ll = NB log-likelihood - pi - softplus(-pi).  Scalar accesses, four passes per row
+// (the row is re-read from L2): this is the option-matrix path, not the benchmarked one.
+struct ZinbExtra {
+    const float* pi;
+    void* dpi;
+    int64_t ldpi, lddpi;
+};
+__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <typename TD, int NT>
+__global__ __launch_bounds__(NT) void zinb_fwd_bwd_kernel(NbArgs a, ZinbExtra z) {
+    extern __shared__ __attribute__((aligned(16))) float dacc[];
+    __shared__ float red[32];
+    const int tid = threadIdx.x;
+    const int64_t G = a.G;
+    const float eps = 1e-8f;
+    for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
+    int cur_pat = -1, flushed = 0;
+    float loss_acc = 0.f;
+    auto flush = [&](int pat) {
+        __syncthreads();
+        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
+        const bool first = !((flushed >> pat) & 1);
+        for (int64_t c = tid; c < G; c += NT) {
+            dst[c] = first ? dacc[c] : dst[c] + dacc[c];
+            dacc[c] = 0.f;
+        }
+        flushed |= 1 << pat;
+        __syncthreads();
+    };
+    for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
+        int has0 = 0, has1 = 0, bad = 0;
+        for (int j = 0; j < a.C; ++j) {
+            const int64_t v = a.cond[row * a.C + j];
+            has0 |= (v == 0);
+            has1 |= (v == 1);
+            bad |= (v < 0) | (v > 1) | (v >= a.C);
+        }
+        if (bad || (!has0 && !has1)) {
+            if (tid == 0) *a.status = 1;
+            continue;
+        }
+        const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
+        if (pat != cur_pat) {
+            if (cur_pat >= 0) flush(cur_pat);
+            cur_pat = pat;
+        }
+        const float* orow = a.logits + row * a.ldl;
+        const float* prow = z.pi + row * z.ldpi;
+        const int64_t srow = a.ridx ? a.ridx[row] : row;
+        const float* xrow = a.x + srow * a.ldx;
+        const uint8_t* grow = a.goodloc + srow * a.ldg;
+        const float sf = a.sizefactor[row];
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float scale = -a.inv_B;
+        float mx = -INFINITY;
+        for (int64_t c = tid; c < G; c += NT) mx = fmaxf(mx, orow[c]);
+        mx = block_max<NT>(mx, red);
+        float sm = 0.f;
+        for (int64_t c = tid; c < G; c += NT) sm += expf(orow[c] - mx);
+        sm = block_sum<NT>(sm, red);
+        const float inv_sum = 1.0f / sm;
+        // per element: ll and its derivatives w.r.t. mu, theta, pi
+        auto eval = [&](int64_t c, float& ll, float& dmu_mu, float& dth, float& dpi, float& p) {
+            p = expf(orow[c] - mx) * inv_sum;
+            const float mu = sf * p, th = tth[c], x = xrow[c], pv = prow[c];
+            const float tm = th + mu + eps, ltm = logf(tm), lte = logf(th + eps);
+            const float sp = softplus_f(-pv);
+            const float ptl = -pv + th * (lte - ltm);
+            const float dptl_dth = (lte - ltm) + th / (th + eps) - th / tm;
+            if (x < eps) {
+                const float sg = sigmoid_f(ptl);
+                ll = softplus_f(ptl) - sp;
+                dmu_mu = sg * (-th / tm) * mu;
+                dth = sg * dptl_dth;
+                dpi = -sg + sigmoid_f(-pv);
+            } else if (x > eps) {
+                const float zt = x + th;
+                ll = tk1[c] - zt * ltm + x * logf(mu + eps) + lgamma_pos(zt) - lgamma_pos(x + 1.0f) - pv - sp;
+                dmu_mu = x * mu / (mu + eps) - zt * mu / tm;
+                dth = tk2[c] - ltm - zt / tm + digamma_pos(zt);
+                dpi = -sigmoid_f(pv);
+            } else {
+                ll = dmu_mu = dth = dpi = 0.f;
+            }
+        };
+        float S = 0.f;
+        for (int64_t c = tid; c < G; c += NT) {
+            float ll, dm, dth, dpi, p;
+            eval(c, ll, dm, dth, dpi, p);
+            S += grow[c] ? scale * dm : 0.f;
+        }
+        S = block_sum<NT>(S, red);
+        TD* drow = reinterpret_cast<TD*>(a.dlogits) + row * a.lddl;
+        TD* dprow = reinterpret_cast<TD*>(z.dpi) + row * z.lddpi;
+        for (int64_t c = tid; c < G; c += NT) {
+            float ll, dm, dth, dpi, p;
+            eval(c, ll, dm, dth, dpi, p);
+            const bool m = grow[c];
+            const float pg = m ? scale * dm : 0.f;
+            st_from_f32<TD>(drow + c, pg - p * S);
+            st_from_f32<TD>(dprow + c, m ? scale * dpi : 0.f);
+            dacc[c] += m ? scale * tth[c] * dth : 0.f;
+            loss_acc += m ? ll : 0.f;
+        }
+    }
+    if (cur_pat >= 0) flush(cur_pat);
+    loss_acc = block_sum<NT>(loss_acc, red);
+    if (tid == 0) {
+        a.part_loss[blockIdx.x] = -a.inv_B * loss_acc;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.part_flag[blockIdx.x * 3 + p] = (flushed >> p) & 1;
+    }
+}
+
 // ---- MSE ---------------------------------------------------------------------------------------------------
 template <typename TD>
 __global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
@@ -690,6 +810,49 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
+    float* part2 = part_loss + ngroups + 32;
+    hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
+                       ngroups, G, part2);
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
+    launch_finalize_sum(part_loss, ngroups, loss_out, st);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
+                                     int64_t ldx, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                                     const float* theta, const int64_t* cond, int C, int64_t B, int64_t G, float inv_B,
+                                     float* loss_out, void* dlogits, void* dpi, int d_dtype, int64_t lddl,
+                                     int64_t lddpi, float* dtheta, float* ws, int32_t* status_dev,
+                                     const int64_t* row_index, void* stream) {
+    C2_CHECK(logits && pi && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dpi && dtheta && ws &&
+                 status_dev, "null pointer");
+    C2_CHECK(d_dtype == C2_F32 || d_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(C >= 1, "ZINB needs at least one condition column (theta is [G,C])");
+    C2_CHECK(ldl >= G && ldpi >= G && ldx >= G && ldg >= G && lddl >= G && lddpi >= G, "leading dimension too small");
+    C2_CHECK(G <= 40000, "G > 40000 genes is not supported (the LDS accumulator holds G floats)");
+    if (B == 0 || G == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
+    float* tab = ws;
+    float* part_dt = tab + 9 * G;
+    int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
+    float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
+    NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
+             nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
+    ZinbExtra z{pi, dpi, ldpi, lddpi};
+    const size_t lds = (size_t)G * sizeof(float);
+    constexpr int NT = 512;
+    if (d_dtype == C2_BF16) {
+        auto k = zinb_fwd_bwd_kernel<bf16_t, NT>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), lds, st, a, z);
+    } else {
+        auto k = zinb_fwd_bwd_kernel<float, NT>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), lds, st, a, z);
+    }
     float* part2 = part_loss + ngroups + 32;
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
                        ngroups, G, part2);

@@ -68,6 +68,7 @@ class StepEngine:
         for i in range(1, len(cfg["cls_hidden"])):
             self.cls.append(_Block(f"cls{i}", f"classifier.HiddenL.L{i}.weight", None, None, f"cls.D{i}", False))
         self.head = "decoder.recon_decoder.0" if cfg["recon_loss"] == "mse" else "decoder.mean_decoder.0"
+        self.head2 = "decoder.dropout_decoder" if cfg["recon_loss"] == "zinb" else None  # ZINB dropout logits
         # Mixed-precision policy of bf16 mode: only the gene-width GEMMs (>= WIDE on either weight dimension:
         # encoder L0 and the decoder output layer, 96.6 % of the FLOPs at 19k genes) take bf16 operands; the
         # narrow hidden GEMMs keep fp32 operands, so the back-propagated signal is rounded to bf16 only where it
@@ -102,6 +103,8 @@ class StepEngine:
     def _readiness_order(self):
         """Parameter names in the order the backward pass finishes their gradients."""
         order = [self.head + ".weight", self.head + ".bias", "theta"]
+        if self.head2:
+            order += [self.head2 + ".weight", self.head2 + ".bias"]
         for blk in reversed(self.dec):
             order += [blk.w, blk.wc]
         order += ["classifier.classifier.0.weight", "classifier.classifier.0.bias"]
@@ -134,6 +137,8 @@ class StepEngine:
         self.grad_flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
         self.grad = {n: self.grad_flat[offs[n]:offs[n] + self.p[n].numel()].view(self.p[n].shape) for n in names}
         first = {self.head + ".weight", self.head + ".bias", "theta"}
+        if self.head2:
+            first |= {self.head2 + ".weight", self.head2 + ".bias"}
         last = {self.enc[0].w, self.enc[0].b, self.enc[0].wc}
         b0 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in first)
         b2 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in last)
@@ -403,8 +408,19 @@ class StepEngine:
             if x is None:
                 raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")
             ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws)
-        else:
-            raise NotImplementedError("recon_loss='zinb' is not built yet (SURVEY.md 8(f) rank 3)")
+        else:  # zinb: second gene-width head for the dropout logits (modules.py:471-477, celligner2.py:286-296)
+            pi = self.buf("pi", (B, G))
+            self._fwd(d, self.head2 + ".weight", pi, bias=self.p[self.head2 + ".bias"].detach())
+            dpi = self.buf("dpi", (B, G), self.head_t)
+            C = cfg["n_conditions"]
+            ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
+            if x is None:
+                xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
+            else:
+                xs, gl, ridx = x, batch["goodloc"], None
+            ops.recon_zinb(logits, pi, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
+                           losses[0:1], dlogits, dpi, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
+                           row_index=ridx)
         # ---- classifier
         classes = batch.get("classes")
         self._has_cls = classes is not None
@@ -464,9 +480,20 @@ class StepEngine:
             ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
             ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
         H1 = self.p[hw].shape[1]
-        dd = self.buf("dhead.da", (self._dgrad_nslab(dlogits, hw), B, H1))
-        self._dgrad(dlogits, hw, dd, alpha=gr)
-        if cfg["recon_loss"] == "nb" and rq("theta"):
+        ns1 = self._dgrad_nslab(dlogits, hw)
+        ns2 = self._dgrad_nslab(dlogits, self.head2 + ".weight") if self.head2 else 0
+        dd = self.buf("dhead.da", (ns1 + ns2, B, H1))
+        self._dgrad(dlogits, hw, dd[:ns1], alpha=gr)
+        if self.head2:  # ZINB: the dropout head's gradients; its dgrad lands in further slabs of the same sum
+            dpi = self._ws["dpi"]
+            h2w, h2b = self.head2 + ".weight", self.head2 + ".bias"
+            if rq(h2w):
+                self._wgrad(dpi, self._dlast, h2w, alpha=gr)
+            if rq(h2b):
+                ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+                ops.bias_cond_grad(dpi, None, self.gbuf(h2b), None, ws, alpha=gr)
+            self._dgrad(dpi, h2w, dd[ns1:], alpha=gr)
+        if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
             gt = self.gbuf("theta")
             gt.zero_()
             ops.axpy(self._ws["dtheta.unit"], gr, gt)
@@ -586,6 +613,8 @@ class StepEngine:
         G = self.cfg["input_dim"]
         logits = self.buf("logits", (B, G))
         self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
+        if self.head2:
+            self._fwd(d, self.head2 + ".weight", self.buf("pi", (B, G)), bias=self.p[self.head2 + ".bias"].detach())
         return logits, self._ws["dec0.act"]
 
     def check_status(self):

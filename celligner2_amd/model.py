@@ -89,8 +89,9 @@ class Decoder(nn.Module):  # modules.py:335-513
             self.recon_decoder = nn.Sequential(_Linear(ls[-2], ls[-1]), _Marker("ReLU"))
         elif recon_loss == "nb":
             self.mean_decoder = nn.Sequential(_Linear(ls[-2], ls[-1]), _Marker("Softmax(dim=-1)"))
-        else:
-            raise NotImplementedError("recon_loss='zinb' is not built yet (SURVEY.md 8(f) rank 3)")
+        else:  # zinb (modules.py:471-477): softmax mean head, then a plain Linear head for the dropout logits
+            self.mean_decoder = nn.Sequential(_Linear(ls[-2], ls[-1]), _Marker("Softmax(dim=-1)"))
+            self.dropout_decoder = _Linear(ls[-2], ls[-1])
 
 
 class Classifier(nn.Module):  # modules.py:516-633
@@ -412,4 +413,6 @@ class Celligner2(nn.Module):
         logits, y1 = eng.decode(latent, c.long().contiguous() if c is not None else None)
         if self.recon_loss == "mse":
             return torch.relu(logits), y1.float().clone()
+        if self.recon_loss == "zinb":  # Decoder.forward returns (mean, dropout logits, y1), modules.py:506-509
+            return torch.softmax(logits, dim=-1), eng._ws["pi"].clone(), y1.float().clone()
         return torch.softmax(logits, dim=-1), y1.float().clone()

@@ -278,6 +278,23 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
                                   stream()))
 
 
+def recon_zinb(logits, pi, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dpi, dtheta, ws, status,
+               row_index=None):
+    L.require_gpu(logits, pi, x, goodloc, dlogits, dpi)
+    B, G = logits.shape
+    C = theta.shape[1]
+    assert tuple(pi.shape) == (B, G) and dlogits.dtype == dpi.dtype and tuple(dpi.shape) == (B, G)
+    assert goodloc.dtype in (torch.bool, torch.uint8) and theta.is_contiguous() and cond.is_contiguous()
+    assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
+    assert ws.numel() >= recon_nb_ws(B, G, C) and sizefactor.dtype == torch.float32 and sizefactor.is_contiguous()
+    assert x.shape[1] == G and goodloc.shape == x.shape and (row_index is not None or x.shape[0] == B)
+    check(lib.c2_recon_zinb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(pi), _row_major(pi, "pi"), ptr(x),
+                                    _row_major(x, "x"), ptr(goodloc), _row_major(goodloc, "goodloc"), ptr(sizefactor),
+                                    ptr(theta), ptr(cond), C, B, G, float(inv_B), ptr(loss_out), ptr(dlogits), ptr(dpi),
+                                    dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"), _row_major(dpi, "dpi"),
+                                    ptr(dtheta), ptr(ws), ptr(status), ptr(row_index), stream()))
+
+
 def recon_mse(logits, x, goodloc, inv_B, loss_out, dlogits, ws):
     L.require_gpu(logits, x, goodloc, dlogits)
     B, G = x.shape

@@ -147,6 +147,17 @@ int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_
                         int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
                         const int64_t* row_index, void* stream);
 
+/* ZINB reconstruction loss, forward and backward (celligner2.py:286-296, losses.py:68-124): as the NB entry point
+ * with a second logit matrix `pi` (decoder.dropout_decoder, modules.py:471-477) and its gradient dpi:
+ *   x < 1e-8: ll = softplus(-pi + theta (log(theta+eps) - log(theta+mu+eps))) - softplus(-pi)
+ *   x > 1e-8: ll = NB log-likelihood - pi - softplus(-pi).
+ * dlogits and dpi share d_dtype.  ws: c2_recon_nb_ws(B,G,C) floats. */
+int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x, int64_t ldx,
+                          const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
+                          const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits,
+                          void* dpi, int d_dtype, int64_t lddl, int64_t lddpi, float* dtheta, float* ws,
+                          int32_t* status_dev, const int64_t* row_index, void* stream);
+
 /* out[b] = sum_g goodloc[b][g] * lgamma(x[b][g] + 1): the data-only term of the NB log-likelihood
  * (losses.py:60-64, `- torch.lgamma(x + 1)`), for c2_recon_nb_fwd_bwd's lgx1_rowsum. */
 int c2_nb_row_const(const float* x, int64_t ldx, const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G,

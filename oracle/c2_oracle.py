@@ -96,6 +96,9 @@ def param_shapes(cfg: Cfg) -> Dict[str, tuple]:
     head = "recon_decoder" if cfg.recon_loss == "mse" else "mean_decoder"
     out[f"decoder.{head}.0.weight"] = (G, dec[-2])
     out[f"decoder.{head}.0.bias"] = (G,)
+    if cfg.recon_loss == "zinb":  # modules.py:471-477: a second, plain Linear head for the dropout logits
+        out["decoder.dropout_decoder.weight"] = (G, dec[-2])
+        out["decoder.dropout_decoder.bias"] = (G,)
     return out
 
 
@@ -201,6 +204,56 @@ def nb_loss(o, x, goodloc, sizefactor, theta, batch):
     d_t = -(m / dt.type(B)) * th * dll_dth
     d_theta = d_t.T @ q
     return recon, d_o, d_theta
+
+
+def _softplus(v):
+    return np.logaddexp(v, 0)
+
+
+def _sigmoid(v):
+    return 0.5 * (1.0 + np.tanh(0.5 * v))
+
+
+def zinb_loss(o, pi, x, goodloc, sizefactor, theta, batch):
+    """celligner2.py:286-296 + losses.py:68-124.  o: mean-head logits (softmax inside), pi: dropout logits.
+    Returns (recon, d_o, d_pi, d_theta) for unit upstream gradient.
+      x < eps : ll = softplus(ptl) - softplus(-pi),   ptl = -pi + theta (log(theta+eps) - log(theta+mu+eps))
+      x > eps : ll = NB log-likelihood - pi - softplus(-pi)"""
+    dt = o.dtype
+    B, G = o.shape
+    C = theta.shape[1]
+    eps = dt.type(1e-8)
+    omax = o.max(1, keepdims=True)
+    e = np.exp(o - omax)
+    p = e / e.sum(1, keepdims=True)
+    mu = p * sizefactor[:, None]
+    q = quirk_onehot(batch, C, dt)
+    th = np.exp(q @ theta.T)
+    l_te = np.log(th + eps)
+    l_tm = np.log(th + mu + eps)
+    sp = _softplus(-pi)
+    ptl = -pi + th * (l_te - l_tm)
+    case_zero = _softplus(ptl) - sp
+    case_nz = (-sp + ptl + x * (np.log(mu + eps) - l_tm) + gammaln(x + th) - gammaln(th) - gammaln(x + 1))
+    z0 = (x < eps).astype(dt)
+    z1 = (x > eps).astype(dt)
+    ll = (z0 * case_zero + z1 * case_nz).astype(dt)
+    m = goodloc.astype(dt)
+    recon = -(ll * m).sum(-1).mean()
+    # backward
+    dptl_dmu = -th / (th + mu + eps)
+    dptl_dth = (l_te - l_tm) + th / (th + eps) - th / (th + mu + eps)
+    s_ptl = _sigmoid(ptl)
+    dll_dmu = z0 * s_ptl * dptl_dmu + z1 * (x / (mu + eps) - (th + x) / (th + mu + eps))
+    dll_dth = z0 * s_ptl * dptl_dth + z1 * (dptl_dth - x / (th + mu + eps) + digamma(x + th) - digamma(th))
+    dll_dpi = z0 * (-s_ptl + _sigmoid(-pi)) + z1 * (-_sigmoid(pi))
+    w = -(m / dt.type(B))
+    gp = w * sizefactor[:, None] * dll_dmu
+    d_o = p * (gp - (p * gp).sum(1, keepdims=True))
+    d_pi = (w * dll_dpi).astype(dt)
+    d_t = w * th * dll_dth
+    d_theta = d_t.T @ q
+    return recon, d_o.astype(dt), d_pi, d_theta.astype(dt)
 
 
 def mse_loss(o, x, goodloc):
@@ -422,6 +475,11 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
         g["theta"] = d_theta
     elif cfg.recon_loss == "mse":
         recon, d_o = mse_loss(o, xin, batch["goodloc"])
+    elif cfg.recon_loss == "zinb":
+        pi = d @ P["decoder.dropout_decoder.weight"].T + P["decoder.dropout_decoder.bias"]
+        recon, d_o, d_pi, d_theta = zinb_loss(o, pi, x, batch["goodloc"], batch["sizefactor"].astype(dt),
+                                              P["theta"], cond_i)
+        g["theta"] = d_theta
     else:
         raise NotImplementedError(cfg.recon_loss)
     kl, dmu_kl, dlv_kl = kl_loss(mu, lv, cfg.use_own_kl)
@@ -447,6 +505,11 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
     g[f"decoder.{head}.0.weight"] = d_o.T @ d
     g[f"decoder.{head}.0.bias"] = d_o.sum(0)
     dd = d_o @ P[f"decoder.{head}.0.weight"]
+    if cfg.recon_loss == "zinb":
+        d_pi = gr * d_pi
+        g["decoder.dropout_decoder.weight"] = d_pi.T @ d
+        g["decoder.dropout_decoder.bias"] = d_pi.sum(0)
+        dd = dd + d_pi @ P["decoder.dropout_decoder.weight"]
     for i in range(nh - 1, 0, -1):
         dd, dW, _, _ = _block_bwd(dd, caches[f"dec{i}"], P[f"decoder.HiddenL.L{i}.weight"], False, False)
         g[f"decoder.HiddenL.L{i}.weight"] = dW

@@ -536,3 +536,28 @@ def test_wgrad_two_part_schedule(by_rows):
     # shapes that fill whole rounds (or are too small) are left to the ordinary path
     assert not eng._wgrad_two_part(dy[:, :256 * 4] if by_rows else dy, a if by_rows else a[:, :256 * 4],
                                    torch.empty((256 * 4, K) if by_rows else (N, 256 * 4), device=DEV), None)
+
+
+@pytest.mark.parametrize("B,G,C,multi", [(6, 200, 2, True), (4, 3001, 3, False), (3, 19000, 2, False)])
+@pytest.mark.parametrize("d_dtype", [torch.float32, torch.bfloat16])
+def test_recon_zinb(B, G, C, multi, d_dtype):
+    """c2_recon_zinb_fwd_bwd vs the oracle (pinned to the reference by tests/golden/zinb_mmd_z.npz)."""
+    ops = _ops()
+    rng = np.random.default_rng(G + B)
+    o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C, multi)
+    x[:, ::3] = 0.0  # plenty of zeros: the zero-inflation branch
+    pi = rng.standard_normal((B, G)).astype(np.float32) * 2
+    recon64, do64, dpi64, dth64 = orc.zinb_loss(o.astype(np.float64), pi.astype(np.float64), x.astype(np.float64), good,
+                                                sf.astype(np.float64), theta.astype(np.float64), cond)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, G, device=DEV, dtype=d_dtype)
+    dpi = torch.empty(B, G, device=DEV, dtype=d_dtype)
+    dth = torch.empty(G, C, device=DEV)
+    ws = torch.empty(ops.recon_nb_ws(B, G, C), device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_zinb(T(o), T(pi), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dpi, dth, ws, status)
+    assert status.item() == 0
+    assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
+    tol = 1e-4 if d_dtype == torch.float32 else 1e-2
+    assert rel(dl, do64) < tol and rel(dpi, dpi64) < tol
+    assert rel(dth, dth64) < 1e-4

@@ -73,6 +73,9 @@ CASES = {
                           1e-3, True),
     "nb_wide_row": (dict(input_dim=19000, hidden_layer_sizes=[16, 8], latent_dim=4, n_cond=2, n_pred=0,
                          recon_loss="nb", dr_rate=0.0, use_mmd=False), 4, False, 1, 1e-3, False),
+    "zinb_mmd_z": (dict(input_dim=88, hidden_layer_sizes=[40, 16], latent_dim=7, n_cond=3, n_pred=3,
+                        recon_loss="zinb", dr_rate=0.0, use_mmd=True, mmd_on="z", beta=20.0), 32, False, 2, 1e-3,
+                   False),
 }
 
 
