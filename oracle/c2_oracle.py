@@ -52,6 +52,7 @@ class Cfg:
     main_dataset: Optional[int] = None  # index into the condition encoder
     betaclass: float = 0.8
     use_ln: bool = True
+    use_bn: bool = False  # BatchNorm1d(affine) instead of LayerNorm (modules.py:298-302,405-413,445-449,557-566,596-600)
 
     def to_json(self):
         return dataclasses.asdict(self)
@@ -99,6 +100,33 @@ def param_shapes(cfg: Cfg) -> Dict[str, tuple]:
     if cfg.recon_loss == "zinb":  # modules.py:471-477: a second, plain Linear head for the dropout logits
         out["decoder.dropout_decoder.weight"] = (G, dec[-2])
         out["decoder.dropout_decoder.bias"] = (G,)
+    if cfg.use_bn:
+        for nm, h in norm_names(cfg).values():
+            out[nm + ".weight"] = (h,)
+            out[nm + ".bias"] = (h,)
+    return out
+
+
+def norm_names(cfg: Cfg) -> Dict[str, tuple]:
+    """block key -> (module name of its norm layer in the reference tree, width)."""
+    hs = list(cfg.hidden_layer_sizes)
+    out = {f"enc{i}": (f"encoder.FC.N{i}", h) for i, h in enumerate(hs)}
+    for i, h in enumerate(hs[::-1]):
+        out[f"dec{i}"] = ("decoder.FirstL.N0" if i == 0 else f"decoder.HiddenL.N{i}", h)
+    for i, h in enumerate(cfg.classifier_hidden_layer_sizes):
+        out[f"cls{i}"] = ("classifier.FirstL.N0" if i == 0 else f"classifier.HiddenL.N{i}", h)
+    return out
+
+
+def buffer_shapes(cfg: Cfg) -> Dict[str, tuple]:
+    """BatchNorm1d buffers of the reference's state_dict (torch.nn.BatchNorm1d: running_mean, running_var,
+    num_batches_tracked)."""
+    out: Dict[str, tuple] = {}
+    if cfg.use_bn:
+        for nm, h in norm_names(cfg).values():
+            out[nm + ".running_mean"] = (h,)
+            out[nm + ".running_var"] = (h,)
+            out[nm + ".num_batches_tracked"] = ()
     return out
 
 
@@ -116,34 +144,65 @@ def dropout_names(cfg: Cfg) -> List[str]:
 # layer block: linear (+bias) (+cond) -> LayerNorm(no affine) -> ReLU -> dropout
 # celligner2/model/modules.py:77-107, 124-130, 298-312
 # ----------------------------------------------------------------------------
-def _block_fwd(a, W, b, cond, Wc, mask, p, use_ln=True):
+def _block_fwd(a, W, b, cond, Wc, mask, p, use_ln=True, bn=None):
+    """bn: None, or dict(weight, bias, running_mean, running_var, batch_stats, track, momentum) for the
+    BatchNorm1d(affine=True, eps 1e-5, momentum 0.1) variant (torch.nn.functional.batch_norm semantics: biased
+    batch variance normalises, the UNBIASED one feeds running_var).  bn["new_running"] is set to the updated
+    (running_mean, running_var) when batch statistics are tracked."""
     h = a @ W.T
     if b is not None:
         h = h + b
     if Wc is not None:
         h = h + cond @ Wc.T  # multi-hot row cast to float (modules.py:324,487)
-    if use_ln:
+    dt = h.dtype.type
+    if bn is not None:
+        if bn["batch_stats"]:
+            n = h.shape[0]
+            mean = h.mean(0, keepdims=True)
+            var = ((h - mean) ** 2).mean(0, keepdims=True)
+            if bn.get("track", True):
+                m = dt(bn.get("momentum", 0.1))
+                bn["new_running"] = ((1 - m) * bn["running_mean"] + m * mean[0],
+                                     (1 - m) * bn["running_var"] + m * var[0] * dt(n / max(n - 1, 1)))
+        else:
+            mean, var = bn["running_mean"][None, :], bn["running_var"][None, :]
+        rstd = 1.0 / np.sqrt(var + dt(1e-5))
+        yhat = (h - mean) * rstd
+        pre = yhat * bn["weight"] + bn["bias"]
+    elif use_ln:
         mean = h.mean(1, keepdims=True)
         var = ((h - mean) ** 2).mean(1, keepdims=True)  # biased, eps 1e-5
-        rstd = 1.0 / np.sqrt(var + h.dtype.type(1e-5))
-        yhat = (h - mean) * rstd
+        rstd = 1.0 / np.sqrt(var + dt(1e-5))
+        pre = yhat = (h - mean) * rstd
     else:
         rstd = np.ones((h.shape[0], 1), h.dtype)
-        yhat = h
-    r = np.maximum(yhat, 0)
+        pre = yhat = h
+    r = np.maximum(pre, 0)
     if mask is not None:
-        out = r * mask / h.dtype.type(1.0 - p)
+        out = r * mask / dt(1.0 - p)
     else:
         out = r
-    return out, (a, cond, yhat, rstd, mask, p, use_ln)
+    return out, dict(a=a, cond=cond, yhat=yhat, rstd=rstd, mask=mask, p=p, use_ln=use_ln, bn=bn, pre=pre)
 
 
 def _block_bwd(dout, cache, W, has_bias, has_cond, need_da=True):
-    a, cond, yhat, rstd, mask, p, use_ln = cache
+    """Returns (da, dW, db, dWc, dgamma, dbeta); the last two are None without BatchNorm."""
+    a, cond, yhat, rstd, mask, p = (cache[k] for k in ("a", "cond", "yhat", "rstd", "mask", "p"))
+    bn = cache["bn"]
     if mask is not None:
         dout = dout * mask / dout.dtype.type(1.0 - p)
-    dy = dout * (yhat > 0)
-    if use_ln:
+    dy = dout * (cache["pre"] > 0)
+    dgam = dbet = None
+    if bn is not None:
+        dgam, dbet = (dy * yhat).sum(0), dy.sum(0)
+        dyh = dy * bn["weight"]
+        if bn["batch_stats"]:
+            m1 = dyh.mean(0, keepdims=True)
+            m2 = (dyh * yhat).mean(0, keepdims=True)
+            dh = (dyh - m1 - yhat * m2) * rstd
+        else:
+            dh = dyh * rstd
+    elif cache["use_ln"]:
         m1 = dy.mean(1, keepdims=True)
         m2 = (dy * yhat).mean(1, keepdims=True)
         dh = (dy - m1 - yhat * m2) * rstd
@@ -153,7 +212,7 @@ def _block_bwd(dout, cache, W, has_bias, has_cond, need_da=True):
     db = dh.sum(0) if has_bias else None
     dWc = dh.T @ cond if has_cond else None
     da = dh @ W if need_da else None
-    return da, dW, db, dWc
+    return da, dW, db, dWc, dgam, dbet
 
 
 # ----------------------------------------------------------------------------
@@ -409,10 +468,13 @@ def classifier_hb_loss(u, y, betaclass):
 # full step: celligner2.py:259-374 forward + explicit backward
 # ----------------------------------------------------------------------------
 def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
-                     gscale=(1.0, 1.0, 1.0, 1.0), want_grads=True, train=True):
+                     gscale=(1.0, 1.0, 1.0, 1.0), want_grads=True, train=True, buffers=None, bn_untracked=()):
     """batch: dict x [B,G], batch [B,C] int, sizefactor [B], classes [B,P] int or
     None, goodloc [B,G] bool.  gscale = upstream gradient of (recon, kl, mmd, ce):
     the trainer uses (1, alpha, 1, 1) (semisupervised.py:66).
+    use_bn: `buffers` holds the BatchNorm running statistics (buffer_shapes); the updated ones come back as
+    out["buffers"].  bn_untracked: norm-module names whose running statistics are not tracked -- the trainer's
+    rule for BatchNorm layers frozen by surgery (trainer.py:307-312: batch statistics still normalise).
     Returns dict(losses=[4], grads={name: array}, z=..., mu=..., lv=...)."""
     P = params
     dt = P["encoder.FC.L0.expr_L.weight"].dtype
@@ -427,6 +489,20 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
     def mk(name):
         return masks.get(name) if (p > 0 and train) else None
 
+    nnames = norm_names(cfg)
+    new_buffers = {k: np.array(v) for k, v in (buffers or {}).items()}
+    bns = {}
+
+    def bn_of(key):
+        if not cfg.use_bn:
+            return None
+        nm = nnames[key][0]
+        bns[key] = dict(name=nm, weight=P[nm + ".weight"], bias=P[nm + ".bias"],
+                        running_mean=np.asarray(buffers[nm + ".running_mean"]).astype(dt),
+                        running_var=np.asarray(buffers[nm + ".running_var"]).astype(dt),
+                        batch_stats=train, track=train and nm not in bn_untracked)
+        return bns[key]
+
     if cfg.applylog and cfg.recon_loss != "mse":
         xin = np.log(1 + x)  # celligner2.py:269-274
     else:
@@ -438,11 +514,12 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
         if i == 0:
             a, caches["enc0"] = _block_fwd(
                 a, P["encoder.FC.L0.expr_L.weight"], P["encoder.FC.L0.expr_L.bias"], cond,
-                P.get("encoder.FC.L0.cond_L.weight") if has_cond else None, mk("enc.D0"), p, cfg.use_ln)
+                P.get("encoder.FC.L0.cond_L.weight") if has_cond else None, mk("enc.D0"), p, cfg.use_ln,
+                bn_of("enc0"))
         else:
             a, caches[f"enc{i}"] = _block_fwd(
                 a, P[f"encoder.FC.L{i}.weight"], P[f"encoder.FC.L{i}.bias"], None, None,
-                mk(f"enc.D{i}"), p, cfg.use_ln)
+                mk(f"enc.D{i}"), p, cfg.use_ln, bn_of(f"enc{i}"))
     henc = a
     mu = henc @ P["encoder.mean_encoder.weight"].T + P["encoder.mean_encoder.bias"]
     lv = henc @ P["encoder.log_var_encoder.weight"].T + P["encoder.log_var_encoder.bias"]
@@ -450,11 +527,12 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
     # ---- decoder (modules.py:484-513)
     d, caches["dec0"] = _block_fwd(
         z, P["decoder.FirstL.L0.expr_L.weight"], None, cond,
-        P.get("decoder.FirstL.L0.cond_L.weight") if has_cond else None, mk("dec.D0"), p, cfg.use_ln)
+        P.get("decoder.FirstL.L0.cond_L.weight") if has_cond else None, mk("dec.D0"), p, cfg.use_ln, bn_of("dec0"))
     y1 = d
     for i in range(1, nh):
         d, caches[f"dec{i}"] = _block_fwd(
-            d, P[f"decoder.HiddenL.L{i}.weight"], None, None, None, mk(f"dec.D{i}"), p, cfg.use_ln)
+            d, P[f"decoder.HiddenL.L{i}.weight"], None, None, None, mk(f"dec.D{i}"), p, cfg.use_ln,
+            bn_of(f"dec{i}"))
     head = "recon_decoder" if cfg.recon_loss == "mse" else "mean_decoder"
     o = d @ P[f"decoder.{head}.0.weight"].T + P[f"decoder.{head}.0.bias"]
     # ---- classifier (modules.py:619-633), only when classes are given
@@ -462,10 +540,10 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
     ncl = len(cfg.classifier_hidden_layer_sizes)
     if classes is not None:
         c, caches["cls0"] = _block_fwd(z, P["classifier.FirstL.L0.weight"], None, None, None,
-                                       mk("cls.D0"), p, cfg.use_ln)
+                                       mk("cls.D0"), p, cfg.use_ln, bn_of("cls0"))
         for i in range(1, ncl):
             c, caches[f"cls{i}"] = _block_fwd(c, P[f"classifier.HiddenL.L{i}.weight"], None, None,
-                                              None, mk(f"cls.D{i}"), p, cfg.use_ln)
+                                              None, mk(f"cls.D{i}"), p, cfg.use_ln, bn_of(f"cls{i}"))
         u = c @ P["classifier.classifier.0.weight"].T + P["classifier.classifier.0.bias"]
     # ---- losses
     g = {}
@@ -495,9 +573,22 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
                y1=y1, logits=o)
     if classes is not None:
         out["class_logits"] = u
+    for bn in bns.values():
+        if "new_running" in bn:
+            nm = bn["name"]
+            new_buffers[nm + ".running_mean"], new_buffers[nm + ".running_var"] = bn["new_running"]
+            new_buffers[nm + ".num_batches_tracked"] = np.asarray(buffers[nm + ".num_batches_tracked"]) + 1
+    out["buffers"] = new_buffers
     if not want_grads:
         return out
     gr, gk, gm, gc = [dt.type(v) for v in gscale]
+
+    def bwd(key, dout, W, has_bias, has_c, need_da=True):
+        da_, dW_, db_, dWc_, dgam, dbet = _block_bwd(dout, caches[key], W, has_bias, has_c, need_da)
+        if dgam is not None:
+            g[nnames[key][0] + ".weight"], g[nnames[key][0] + ".bias"] = dgam, dbet
+        return da_, dW_, db_, dWc_
+
     # ---- backward: decoder
     d_o = gr * d_o
     if "theta" in g:
@@ -511,11 +602,11 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
         g["decoder.dropout_decoder.bias"] = d_pi.sum(0)
         dd = dd + d_pi @ P["decoder.dropout_decoder.weight"]
     for i in range(nh - 1, 0, -1):
-        dd, dW, _, _ = _block_bwd(dd, caches[f"dec{i}"], P[f"decoder.HiddenL.L{i}.weight"], False, False)
+        dd, dW, _, _ = bwd(f"dec{i}", dd, P[f"decoder.HiddenL.L{i}.weight"], False, False)
         g[f"decoder.HiddenL.L{i}.weight"] = dW
     if cfg.use_mmd and cfg.mmd_on != "z":
         dd = dd + gm * d_mmd
-    dz, dW, _, dWc = _block_bwd(dd, caches["dec0"], P["decoder.FirstL.L0.expr_L.weight"], False, has_cond)
+    dz, dW, _, dWc = bwd("dec0", dd, P["decoder.FirstL.L0.expr_L.weight"], False, has_cond)
     g["decoder.FirstL.L0.expr_L.weight"] = dW
     if has_cond:
         g["decoder.FirstL.L0.cond_L.weight"] = dWc
@@ -528,9 +619,9 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
         g["classifier.classifier.0.bias"] = du.sum(0)
         dc = du @ P["classifier.classifier.0.weight"]
         for i in range(ncl - 1, 0, -1):
-            dc, dW, _, _ = _block_bwd(dc, caches[f"cls{i}"], P[f"classifier.HiddenL.L{i}.weight"], False, False)
+            dc, dW, _, _ = bwd(f"cls{i}", dc, P[f"classifier.HiddenL.L{i}.weight"], False, False)
             g[f"classifier.HiddenL.L{i}.weight"] = dW
-        dzc, dW, _, _ = _block_bwd(dc, caches["cls0"], P["classifier.FirstL.L0.weight"], False, False)
+        dzc, dW, _, _ = bwd("cls0", dc, P["classifier.FirstL.L0.weight"], False, False)
         g["classifier.FirstL.L0.weight"] = dW
         dz = dz + dzc
     # ---- reparam + KL backward
@@ -543,11 +634,10 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
     g["encoder.log_var_encoder.bias"] = dlv.sum(0)
     da = dmu @ P["encoder.mean_encoder.weight"] + dlv @ P["encoder.log_var_encoder.weight"]
     for i in range(nh - 1, 0, -1):
-        da, dW, db, _ = _block_bwd(da, caches[f"enc{i}"], P[f"encoder.FC.L{i}.weight"], True, False)
+        da, dW, db, _ = bwd(f"enc{i}", da, P[f"encoder.FC.L{i}.weight"], True, False)
         g[f"encoder.FC.L{i}.weight"] = dW
         g[f"encoder.FC.L{i}.bias"] = db
-    _, dW, db, dWc = _block_bwd(da, caches["enc0"], P["encoder.FC.L0.expr_L.weight"], True, has_cond,
-                                need_da=False)
+    _, dW, db, dWc = bwd("enc0", da, P["encoder.FC.L0.expr_L.weight"], True, has_cond, need_da=False)
     g["encoder.FC.L0.expr_L.weight"] = dW
     g["encoder.FC.L0.expr_L.bias"] = db
     if has_cond:

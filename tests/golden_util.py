@@ -35,7 +35,14 @@ def cfg_from_meta(meta):
         recon_loss=kw["recon_loss"], dr_rate=kw["dr_rate"], use_own_kl=kw.get("use_own_kl", False),
         applylog=kw.get("applylog", True), use_mmd=kw.get("use_mmd", False), mmd_on=kw.get("mmd_on", "z"),
         mmd_boundary=kw.get("mmd_boundary"), beta=kw.get("beta", 1.0), main_dataset=meta.get("main_dataset"),
-        betaclass=kw.get("betaclass", 0.8))
+        betaclass=kw.get("betaclass", 0.8), use_ln=kw.get("use_ln", True), use_bn=kw.get("use_bn", False))
+
+
+def split_state(z, cfg):
+    """The fixture's initial state_dict as (parameters, BatchNorm buffers)."""
+    sd = group(z, "p0/")
+    bnames = set(orc.buffer_shapes(cfg))
+    return {k: v for k, v in sd.items() if k not in bnames}, {k: v for k, v in sd.items() if k in bnames}
 
 
 def group(z, prefix):
@@ -47,3 +54,15 @@ def relerr(a, b):
     b = np.asarray(b, np.float64)
     den = max(np.abs(b).max(), 1e-30) if b.size else 1.0
     return float(np.abs(a - b).max() / den) if b.size else 0.0
+
+
+def grad_err(name, got, ref, cfg, all_ref):
+    """Max-norm relative error of one gradient tensor.  With BatchNorm the batch sum of every gradient that flows
+    back through a norm layer is analytically ZERO (the batch mean is subtracted again), so bias gradients are
+    exact zeros (a Linear feeding a norm layer) or the small remainder of a cancelling sum (the encoder heads);
+    the reference's fp32 result is rounding noise at the scale of the summed terms there, and the error is taken
+    relative to the larger of the tensor itself and the same module's weight gradient."""
+    if getattr(cfg, "use_bn", False) and name.endswith(".bias") and name[:-4] + "weight" in all_ref:
+        scale = max(np.abs(all_ref[name[:-4] + "weight"]).max(), np.abs(ref).max())
+        return float(np.abs(np.asarray(got, np.float64) - ref).max() / scale)
+    return relerr(got, ref)

@@ -15,7 +15,9 @@ TOL = 1e-4
 def test_step_matches_reference(name, dtype):
     z, meta = gu.load(name)
     cfg = gu.cfg_from_meta(meta)
-    params = {k: v.astype(dtype) for k, v in gu.group(z, "p0/").items()}
+    params, buffers = gu.split_state(z, cfg)
+    params = {k: v.astype(dtype) for k, v in params.items()}
+    assert set(buffers) == set(orc.buffer_shapes(cfg))
     assert set(params) == set(orc.param_shapes(cfg)), "state_dict key set differs from the reference"
     for k, shp in orc.param_shapes(cfg).items():
         assert params[k].shape == shp
@@ -25,14 +27,18 @@ def test_step_matches_reference(name, dtype):
     for s in range(meta["n_steps"]):
         masks = {k: v.astype(dtype) for k, v in gu.group(z, f"s{s}/mask/").items()}
         out = orc.forward_backward(params, cfg, batch, z[f"s{s}/eps"], masks,
-                                   gscale=(1.0, meta["alpha"], 1.0, 1.0))
+                                   gscale=(1.0, meta["alpha"], 1.0, 1.0), buffers=buffers,
+                                   bn_untracked=meta.get("bn_untracked", ()))
+        buffers = out["buffers"]
+        for k, b in gu.group(z, f"s{s}/buffer/").items():
+            assert gu.relerr(buffers[k], b) < TOL, (k, s)
         ref_losses = z[f"s{s}/losses"]
         for i in range(4):
             assert abs(out["losses"][i] - ref_losses[i]) <= TOL * max(abs(ref_losses[i]), 1.0), (i, out["losses"], ref_losses)
         ref_grads = gu.group(z, f"s{s}/grad/")
         assert set(ref_grads) <= set(out["grads"])
         for k, g in ref_grads.items():
-            assert gu.relerr(out["grads"][k], g) < TOL, (k, gu.relerr(out["grads"][k], g))
+            assert gu.grad_err(k, out["grads"][k], g, cfg, ref_grads) < TOL, (k, gu.relerr(out["grads"][k], g))
         grads = {k: out["grads"][k] for k in ref_grads}  # only what autograd reached
         orc.adam_step(params, grads, state, names=[k for k in trainable if k in grads], **{
             "lr": meta["adam"]["lr"], "eps": meta["adam"]["eps"], "weight_decay": meta["adam"]["weight_decay"]})

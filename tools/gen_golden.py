@@ -76,6 +76,14 @@ CASES = {
     "zinb_mmd_z": (dict(input_dim=88, hidden_layer_sizes=[40, 16], latent_dim=7, n_cond=3, n_pred=3,
                         recon_loss="zinb", dr_rate=0.0, use_mmd=True, mmd_on="z", beta=20.0), 32, False, 2, 1e-3,
                    False),
+    # BatchNorm1d variant (modules.py:298-302 etc.): affine parameters, batch statistics, running-stat buffers
+    "nb_bn_mmd_dropout": (dict(input_dim=104, hidden_layer_sizes=[40, 24], latent_dim=9, n_cond=3, n_pred=4,
+                               recon_loss="nb", dr_rate=0.05, use_mmd=True, mmd_on="y", beta=50.0, use_bn=True,
+                               classifier_hidden_layer_sizes=[32, 16]), 40, False, 2, 1e-3, False),
+    # surgery freeze with BatchNorm: the trainer's per-iteration rule (trainer.py:305-312) is applied by the harness
+    "nb_bn_surgery_frozen": (dict(input_dim=72, hidden_layer_sizes=[32, 16], latent_dim=8, n_cond=3, n_pred=4,
+                                  recon_loss="nb", dr_rate=0.0, use_mmd=True, mmd_on="z", beta=100.0, use_bn=True),
+                             30, False, 2, 1e-3, True),
 }
 
 
@@ -99,6 +107,11 @@ def run_case(ns, name, spec, seed):
         for n_, p_ in model.named_parameters():
             if n_.endswith("bias"):
                 p_.add_(0.05 * torch.randn_like(p_))
+        for m_ in model.modules():  # BatchNorm: non-trivial affine parameters and running statistics
+            if isinstance(m_, torch.nn.BatchNorm1d):
+                m_.weight.add_(0.2 * torch.randn_like(m_.weight))
+                m_.running_mean.add_(0.1 * torch.randn_like(m_.running_mean))
+                m_.running_var.mul_(1 + 0.3 * torch.rand_like(m_.running_var))
     if frozen:  # othermodels/base/_base.py:342-354 (freeze_expression=True)
         model.freeze = True
         for n_, p_ in model.named_parameters():
@@ -159,6 +172,11 @@ def run_case(ns, name, spec, seed):
             rec["masks"].clear()
             rec["eps"].clear()
             tb = {k: torch.tensor(v) for k, v in batch.items()}  # fresh `classes` each step
+            if model.freeze:  # what Trainer.on_iteration does before every loss (trainer.py:305-312)
+                for m_ in model.modules():
+                    if isinstance(m_, torch.nn.BatchNorm1d) and not m_.weight.requires_grad:
+                        m_.affine = False
+                        m_.track_running_stats = False
             recon, kl, mmd, ce = model(**tb)
             loss = recon + alpha * kl + mmd + ce
             opt.zero_grad()
@@ -174,6 +192,8 @@ def run_case(ns, name, spec, seed):
                 if p_.grad is not None:
                     arrays[f"s{step}/grad/{n_}"] = p_.grad.numpy().copy()
                 arrays[f"s{step}/param/{n_}"] = p_.detach().numpy().copy()
+            for n_, b_ in model.named_buffers():
+                arrays[f"s{step}/buffer/{n_}"] = b_.detach().numpy().copy()
             if "classes" in batch:
                 arrays[f"s{step}/classes_after"] = tb["classes"].numpy().copy()
         if name == "nb_wide_row":
@@ -190,6 +210,8 @@ def run_case(ns, name, spec, seed):
             model_kwargs=kw, n_conditions=C, n_predictors=P, main_dataset=main,
             adam=dict(lr=1e-3, eps=0.01, weight_decay=0.04, betas=[0.9, 0.999]),
             trainable=[n_ for n_, p_ in model.named_parameters() if p_.requires_grad],
+            bn_untracked=[n_ for n_, m_ in model.named_modules()
+                          if isinstance(m_, torch.nn.BatchNorm1d) and not m_.track_running_stats],
             torch_version=torch.__version__,
             patches=["recorded dropout/eps draws", "mse masked-sum wrapper (SURVEY Appendix B.2)"],
         )
