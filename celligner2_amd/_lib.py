@@ -41,6 +41,12 @@ _SIGS = {
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
     "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp, vp]),
     "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp, vp]),
+    "c2_bn_ws": (sz, [i64, i64]),
+    "c2_bn_stats": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, i64, i64, vp, vp, vp, vp]),
+    "c2_bn_fwd": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, f32, i32, f32, vp, f32, i64, i64, vp, i32, i64, vp,
+                        vp, vp]),
+    "c2_bn_bwd_reduce": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "c2_bn_bwd": (i32, [vp, vp, vp, i64, i32, vp, vp, i64, i64, vp, i32, i64, vp, vp]),
     "c2_bias_cond_grad_ws": (sz, [i64, i64, i32]),
     "c2_bias_cond_grad": (i32, [vp, i32, i64, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp]),
     "c2_reduce_ws": (sz, []),

@@ -22,9 +22,10 @@ F32 = torch.float32
 class _Block:
     """Linear (+bias) (+cond) -> LayerNorm -> ReLU -> Dropout (modules.py:77-107,124-130,298-312)."""
 
-    def __init__(self, name, w, b, wc, drop_name, use_cond):
+    def __init__(self, name, w, b, wc, drop_name, use_cond, norm=None):
         self.name = name  # e.g. "enc0"
         self.w, self.b, self.wc = w, b, wc  # parameter NAMES (b / wc may be None)
+        self.norm = norm  # use_bn: module name of the block's BatchNorm1d (its .weight / .bias are parameters)
         self.drop_name = drop_name
         self.use_cond = use_cond
         self.gt = F32     # operand dtype of this block's own GEMMs (fwd input, dh, weight)
@@ -32,8 +33,9 @@ class _Block:
 
 
 class StepEngine:
-    def __init__(self, cfg, params, precision="fp32"):
-        """cfg: dict of model options (see model.Celligner2._cfg); params: {name: Parameter}."""
+    def __init__(self, cfg, params, precision="fp32", bn_modules=None):
+        """cfg: dict of model options (see model.Celligner2._cfg); params: {name: Parameter};
+        bn_modules: {module name: BatchNorm1d holder} when cfg["use_bn"]."""
         assert precision in ("fp32", "bf16")
         self.cfg = cfg
         self.p = params
@@ -50,23 +52,35 @@ class StepEngine:
         self._touched = set()
         self.world_size, self.rank = 1, 0
         self.comm = None  # set by parallel.DataParallelStep
+        self.bn = dict(bn_modules or {})
+        self.use_bn = bool(cfg.get("use_bn"))
         nh = len(cfg["hidden"])
         C = cfg["n_conditions"]
+        nm = (lambda s: s) if self.use_bn else (lambda s: None)  # noqa: E731
         self.enc = []
         for i in range(nh):
             if i == 0:
                 self.enc.append(_Block("enc0", "encoder.FC.L0.expr_L.weight", "encoder.FC.L0.expr_L.bias",
-                                       "encoder.FC.L0.cond_L.weight" if C else None, "enc.D0", bool(C)))
+                                       "encoder.FC.L0.cond_L.weight" if C else None, "enc.D0", bool(C),
+                                       nm("encoder.FC.N0")))
             else:
                 self.enc.append(_Block(f"enc{i}", f"encoder.FC.L{i}.weight", f"encoder.FC.L{i}.bias", None,
-                                       f"enc.D{i}", False))
+                                       f"enc.D{i}", False, nm(f"encoder.FC.N{i}")))
         self.dec = [_Block("dec0", "decoder.FirstL.L0.expr_L.weight", None,
-                           "decoder.FirstL.L0.cond_L.weight" if C else None, "dec.D0", bool(C))]
+                           "decoder.FirstL.L0.cond_L.weight" if C else None, "dec.D0", bool(C),
+                           nm("decoder.FirstL.N0"))]
         for i in range(1, nh):
-            self.dec.append(_Block(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, f"dec.D{i}", False))
-        self.cls = [_Block("cls0", "classifier.FirstL.L0.weight", None, None, "cls.D0", False)]
+            self.dec.append(_Block(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, f"dec.D{i}", False,
+                                   nm(f"decoder.HiddenL.N{i}")))
+        self.cls = [_Block("cls0", "classifier.FirstL.L0.weight", None, None, "cls.D0", False,
+                           nm("classifier.FirstL.N0"))]
         for i in range(1, len(cfg["cls_hidden"])):
-            self.cls.append(_Block(f"cls{i}", f"classifier.HiddenL.L{i}.weight", None, None, f"cls.D{i}", False))
+            self.cls.append(_Block(f"cls{i}", f"classifier.HiddenL.L{i}.weight", None, None, f"cls.D{i}", False,
+                                   nm(f"classifier.HiddenL.N{i}")))
+        for chain in (self.enc, self.dec, self.cls):
+            for blk in chain:
+                if blk.norm and blk.norm not in self.bn:
+                    raise ValueError(f"use_bn: no BatchNorm module given for {blk.norm}")
         self.head = "decoder.recon_decoder.0" if cfg["recon_loss"] == "mse" else "decoder.mean_decoder.0"
         self.head2 = "decoder.dropout_decoder" if cfg["recon_loss"] == "zinb" else None  # ZINB dropout logits
         # Mixed-precision policy of bf16 mode: only the gene-width GEMMs (>= WIDE on either weight dimension:
@@ -105,15 +119,16 @@ class StepEngine:
         order = [self.head + ".weight", self.head + ".bias", "theta"]
         if self.head2:
             order += [self.head2 + ".weight", self.head2 + ".bias"]
+        gb = lambda blk: [blk.norm + ".weight", blk.norm + ".bias"] if blk.norm else []  # noqa: E731
         for blk in reversed(self.dec):
-            order += [blk.w, blk.wc]
+            order += gb(blk) + [blk.w, blk.wc]
         order += ["classifier.classifier.0.weight", "classifier.classifier.0.bias"]
         for blk in reversed(self.cls):
-            order += [blk.w]
+            order += gb(blk) + [blk.w]
         order += ["encoder.mean_encoder.weight", "encoder.mean_encoder.bias", "encoder.log_var_encoder.weight",
                   "encoder.log_var_encoder.bias"]
         for blk in reversed(self.enc):
-            order += [blk.w, blk.b, blk.wc]
+            order += gb(blk) + [blk.w, blk.b, blk.wc]
         seen, out = set(), []
         for n in order:
             if n and n in self.p and n not in seen:
@@ -140,6 +155,8 @@ class StepEngine:
         if self.head2:
             first |= {self.head2 + ".weight", self.head2 + ".bias"}
         last = {self.enc[0].w, self.enc[0].b, self.enc[0].wc}
+        if self.enc[0].norm:
+            last |= {self.enc[0].norm + ".weight", self.enc[0].norm + ".bias"}
         b0 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in first)
         b2 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in last)
         self.buckets = [(0, b0), (b0, total - b2), (total - b2, total)]
@@ -303,10 +320,41 @@ class StepEngine:
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if (train and p > 0) else None
         planes = self._tail_planes(blk.name + ".act.pl", act)
-        ops.epilogue_fwd(y, self.p[blk.b].detach() if blk.b else None, cond if blk.use_cond else None,
-                         self.p[blk.wc].detach() if blk.wc else None, mask, p if mask is not None else 0.0,
+        bias = self.p[blk.b].detach() if blk.b else None
+        wc = self.p[blk.wc].detach() if blk.wc else None
+        if blk.norm:
+            self._bn_fwd(blk, y, bias, cond if blk.use_cond else None, wc, mask, p if mask is not None else 0.0, act,
+                         planes, train)
+            return act
+        ops.epilogue_fwd(y, bias, cond if blk.use_cond else None, wc, mask, p if mask is not None else 0.0,
                          self.cfg["use_ln"], act, yhat, rstd, planes=planes)
         return act
+
+    def _bn_fwd(self, blk, y, bias, cond, wc, mask, p, act, planes, train):
+        """BatchNorm1d tail (modules.py:298-302): statistics of the (global) batch in train mode, the running ones
+        in eval mode.  torch.nn.BatchNorm1d.forward: running statistics move only while training AND
+        track_running_stats (the trainer clears it on layers frozen by surgery, trainer.py:307-312)."""
+        _, B, H = y.shape
+        mod = self.bn[blk.norm]
+        if mod.momentum is None:
+            raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is outside the path")
+        if mod.running_mean is None:
+            raise NotImplementedError("BatchNorm1d without running-statistic buffers is outside the path")
+        h = self.buf(blk.name + ".yhat", (B, H))  # pre-norm values, normalised in place by bn_fwd
+        stats = self.buf(blk.name + ".bnstats", (2, H))
+        part = self.buf(blk.name + ".bnpart", (1, 2, H))
+        ops.bn_stats(y, bias, cond, wc, h, part[0], self.buf(f"bn.ws.{B}x{H}", (ops.bn_ws(B, H),)))
+        parts, total = None, B
+        if train:
+            parts = part
+            if self.comm is not None and self.world_size > 1:
+                parts = self.comm.allgather_stats(part[0])
+                total = B * self.world_size
+        self._bn_total = getattr(self, "_bn_total", {})
+        self._bn_total[blk.name] = (total, bool(train))
+        ops.bn_fwd(h, parts, B, total, self.p[blk.norm + ".weight"].detach(), self.p[blk.norm + ".bias"].detach(),
+                   mod.running_mean, mod.running_var, mod.num_batches_tracked, mod.momentum,
+                   train and mod.track_running_stats, mask, p, act, stats, planes=planes, eps=mod.eps)
 
     def _block_bwd(self, blk, dact, a_in, cond, masks, need_da, out_slabs=None, extra=None, extra_scale=None):
         """dact: fp32 [B,H] or slabs.  Returns the slabs of d(a_in) (or None)."""
@@ -316,8 +364,12 @@ class StepEngine:
         mask = masks.get(blk.drop_name) if p > 0 else None
         dh = self.buf(blk.name + ".dh", (B, H), blk.gt)
         planes = self._tail_planes(blk.name + ".dh.pl", dh)
-        ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"], self._ws[blk.name + ".yhat"],
-                         self._ws[blk.name + ".rstd"], dh, extra=extra, extra_scale=extra_scale, planes=planes)
+        if blk.norm:
+            self._bn_bwd(blk, dact, mask, p if mask is not None else 0.0, dh, planes, extra, extra_scale)
+        else:
+            ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"],
+                             self._ws[blk.name + ".yhat"], self._ws[blk.name + ".rstd"], dh, extra=extra,
+                             extra_scale=extra_scale, planes=planes)
         if self.p[blk.w].requires_grad:
             self._wgrad(dh, a_in, blk.w)
         need_b = blk.b is not None and self.p[blk.b].requires_grad
@@ -334,6 +386,22 @@ class StepEngine:
             out_slabs = self.buf(blk.name + ".da", (self._dgrad_nslab(dh, blk.w), B, K))
         self._dgrad(dh, blk.w, out_slabs)
         return out_slabs
+
+    def _bn_bwd(self, blk, dact, mask, p, dh, planes, extra, extra_scale):
+        B, H = dh.shape
+        gn, bn_ = blk.norm + ".weight", blk.norm + ".bias"
+        gamma, beta = self.p[gn].detach(), self.p[bn_].detach()
+        total, batch_stats = self._bn_total[blk.name]
+        dy = self.buf(f"bn.dy.{B}x{H}", (B, H))
+        sums = self.buf(blk.name + ".bnsums", (2, H))
+        ops.bn_bwd_reduce(dact, mask, p, self._ws[blk.name + ".yhat"], gamma, beta, dy, sums,
+                          self.gbuf(gn) if self.p[gn].requires_grad else None,
+                          self.gbuf(bn_) if self.p[bn_].requires_grad else None,
+                          self.buf(f"bn.ws.{B}x{H}", (ops.bn_ws(B, H),)), extra=extra, extra_scale=extra_scale)
+        if batch_stats and self.comm is not None and self.world_size > 1:
+            self.comm.allreduce_scalars(sums)  # dgamma / dbeta above stay local sums: the arena all-reduce adds them
+        ops.bn_bwd(dy, self._ws[blk.name + ".yhat"], sums, total, batch_stats, gamma, self._ws[blk.name + ".bnstats"],
+                   dh, planes=planes)
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch, eps, masks, train=True, save=True, classes_given=True):
@@ -561,6 +629,7 @@ class StepEngine:
     def _first_trainable_enc(self):
         for i, blk in enumerate(self.enc):
             names = [blk.w] + ([blk.b] if blk.b else []) + ([blk.wc] if blk.wc else [])
+            names += [blk.norm + ".weight", blk.norm + ".bias"] if blk.norm else []
             if any(self.p[n].requires_grad for n in names):
                 return i
         return len(self.enc)

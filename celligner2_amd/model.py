@@ -37,6 +37,14 @@ class _Marker(nn.Module):
         return self.what
 
 
+class _BatchNorm(nn.BatchNorm1d):
+    """nn.BatchNorm1d(affine=True) as the holder of weight, bias, running_mean, running_var and num_batches_tracked
+    (same state_dict keys); `track_running_stats` is read by the engine (the trainer clears it on frozen layers)."""
+
+    def forward(self, inp):  # pragma: no cover
+        raise RuntimeError("celligner2_amd sub-modules hold parameters only; call the Celligner2 module")
+
+
 class CondLayers(nn.Module):  # modules.py:39-130 (MaskedCondLayers / CondLayers)
     def __init__(self, n_in, n_out, n_cond, bias):
         super().__init__()
@@ -47,9 +55,9 @@ class CondLayers(nn.Module):  # modules.py:39-130 (MaskedCondLayers / CondLayers
 
 
 def _norm_act_drop(seq, i, size, use_bn, use_ln, use_dr, dr_rate):
-    if use_bn:
-        raise NotImplementedError("use_bn=True (BatchNorm1d) is not built yet (SURVEY.md 8(f) rank 3)")
-    if use_ln:
+    if use_bn:  # modules.py:298-302: BatchNorm wins over LayerNorm; the module holds weight / bias / running stats
+        seq.add_module(f"N{i}", _BatchNorm(size))
+    elif use_ln:
         seq.add_module(f"N{i}", _Marker(f"LayerNorm({size}, elementwise_affine=False)"))
     seq.add_module(f"A{i}", _Marker("ReLU"))
     if use_dr:
@@ -262,7 +270,7 @@ class Celligner2(nn.Module):
             use_own_kl=bool(self.use_own_kl), applylog=bool(self.applylog), use_mmd=bool(self.use_mmd),
             mmd_on=self.mmd_on, mmd_boundary=self.mmd_boundary, beta=float(self.beta),
             main_dataset=(self.condition_encoder[self.main_dataset] if self.main_dataset else None),
-            betaclass=float(self.betaclass), use_ln=bool(self.use_ln))
+            betaclass=float(self.betaclass), use_ln=bool(self.use_ln), use_bn=bool(self.use_bn))
 
     def _engine(self) -> StepEngine:
         params = dict(self.named_parameters())
@@ -272,10 +280,12 @@ class Celligner2(nn.Module):
                                 "(model.cuda()); there is no CPU path")
         eng = self.__dict__["_eng"]
         cfg = self._cfg()
+        bns = {n: m for n, m in self.named_modules() if isinstance(m, _BatchNorm)}
         stale = (eng is None or eng.dev != dev or eng.cfg != cfg or eng.precision != self.precision
-                 or any(eng.p.get(n) is not p for n, p in params.items()) or len(eng.p) != len(params))
+                 or any(eng.p.get(n) is not p for n, p in params.items()) or len(eng.p) != len(params)
+                 or any(eng.bn.get(n) is not m or m.running_mean.device != dev for n, m in bns.items()))
         if stale:
-            eng = StepEngine(cfg, params, self.precision)
+            eng = StepEngine(cfg, params, self.precision, bn_modules=bns)
             if self.world is not None:
                 self.world.attach(eng)
             self.__dict__["_eng"] = eng

@@ -207,6 +207,98 @@ def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_sca
     return dh
 
 
+def bn_ws(B, H):
+    return int(lib.c2_bn_ws(B, H))
+
+
+def _f32c(t, shape, name):
+    assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape), name
+
+
+def bn_stats(y, bias, cond, wc, h_out, part_out, ws):
+    """Pre-norm h = slabs + bias + condition columns, and the local per-column (mean, M2) partial [2,H]."""
+    L.require_gpu(y, h_out, part_out, ws)
+    yt, ldy, ns, ss, B, H = _slabs(y)
+    assert y.dtype == torch.float32
+    _f32c(h_out, (B, H), "h_out")
+    _f32c(part_out, (2, H), "part_out")
+    assert ws.dtype == torch.float32 and ws.numel() >= bn_ws(B, H)
+    C = 0
+    if cond is not None and wc is not None:
+        assert cond.dtype == torch.int64 and cond.is_contiguous() and cond.shape[0] == B
+        C = cond.shape[1]
+        assert tuple(wc.shape) == (H, C) and wc.dtype == torch.float32
+    if bias is not None:
+        _f32c(bias, (H,), "bias")
+    check(lib.c2_bn_stats(ptr(yt), ldy, ns, ss, ptr(bias), ptr(cond) if C else None, C, ptr(wc) if C else None,
+                          wc.stride(0) if C else 0, B, H, ptr(h_out), ptr(part_out), ptr(ws), stream()))
+    return part_out
+
+
+def bn_fwd(h, parts, rows_per_part, total_rows, gamma, beta, running_mean, running_var, num_batches_tracked,
+           momentum, update_running, mask, p_drop, act, stats_out, planes=None, eps=1e-5):
+    """parts: [n,2,H] partials (None: eval mode, the running statistics normalise).  h becomes yhat in place."""
+    L.require_gpu(h, act, stats_out)
+    B, H = h.shape
+    _f32c(h, (B, H), "h")
+    _f32c(gamma, (H,), "gamma")
+    _f32c(beta, (H,), "beta")
+    _f32c(stats_out, (2, H), "stats_out")
+    n = 0
+    if parts is not None:
+        n = parts.shape[0]
+        _f32c(parts, (n, 2, H), "parts")
+    for t, nm in ((running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _f32c(t, (H,), nm)
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.numel() == 1
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (B, H)
+    assert tuple(act.shape) == (B, H)
+    check(lib.c2_bn_fwd(ptr(h), ptr(parts), n, int(rows_per_part), int(total_rows), ptr(gamma), ptr(beta),
+                        ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
+                        int(bool(update_running)), float(eps), ptr(mask), float(p_drop), B, H, ptr(act),
+                        dt_code(act.dtype), _row_major(act, "act"), ptr(stats_out), _planes_arg(planes, B, H), stream()))
+    return act
+
+
+def bn_bwd_reduce(da, mask, p_drop, yhat, gamma, beta, dy_out, sums_out, dgamma, dbeta, ws, extra=None,
+                  extra_scale=None):
+    L.require_gpu(da, dy_out, sums_out, ws)
+    dt, ldda, ns, ss, B, H = _slabs(da)
+    assert da.dtype == torch.float32
+    _f32c(yhat, (B, H), "yhat")
+    _f32c(dy_out, (B, H), "dy_out")
+    _f32c(sums_out, (2, H), "sums_out")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        if t is not None:
+            _f32c(t, (H,), nm)
+    assert ws.dtype == torch.float32 and ws.numel() >= bn_ws(B, H)
+    if extra is not None:
+        assert extra.dtype == torch.float32 and tuple(extra.shape) == (B, H)
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (B, H)
+    check(lib.c2_bn_bwd_reduce(ptr(dt), ldda, ns, ss, ptr(extra), extra.stride(0) if extra is not None else 0,
+                               ptr(extra_scale), ptr(mask), float(p_drop), ptr(yhat), ptr(gamma), ptr(beta), B, H,
+                               ptr(dy_out), ptr(sums_out), ptr(dgamma), ptr(dbeta), ptr(ws), stream()))
+    return sums_out
+
+
+def bn_bwd(dy, yhat, sums, total_rows, batch_stats, gamma, stats, dh, planes=None):
+    L.require_gpu(dy, dh)
+    B, H = dy.shape
+    _f32c(dy, (B, H), "dy")
+    _f32c(yhat, (B, H), "yhat")
+    _f32c(sums, (2, H), "sums")
+    _f32c(stats, (2, H), "stats")
+    _f32c(gamma, (H,), "gamma")
+    assert tuple(dh.shape) == (B, H)
+    check(lib.c2_bn_bwd(ptr(dy), ptr(yhat), ptr(sums), int(total_rows), int(bool(batch_stats)), ptr(gamma), ptr(stats),
+                        B, H, ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), _planes_arg(planes, B, H), stream()))
+    return dh
+
+
 def bias_cond_grad_ws(B, H, C):
     return int(lib.c2_bias_cond_grad_ws(B, H, C))
 

@@ -8,7 +8,10 @@ result equals the reference's step on the GLOBAL batch:
   * MMD couples all rows: z (or y1) and the condition rows are all-gathered, each rank evaluates the kernel
     blocks (own rows x all rows).  K is symmetric, so that row block already holds the complete gradient of the
     rank's own rows: there is NO backward collective for the MMD;
-  * the four loss scalars are SUM all-reduced for logging.
+  * the four loss scalars are SUM all-reduced for logging;
+  * use_bn: the per-column (mean, M2) partials [2,H] of every BatchNorm layer are all-gathered in the forward and
+    combined by the kernel (Chan), the column sums [2,H] of its backward are SUM all-reduced -- SyncBN, so that the
+    statistics are those of the global batch.
 Gradient all-reduce runs per bucket of the engine's flat gradient arena, in backward-readiness order, on a side
 stream, so the decoder-output bucket (the first 78 MB at 19k genes x 1024) overlaps the rest of the backward.
 """
@@ -54,6 +57,13 @@ class DataParallelStep:
         dist.all_gather_into_tensor(feat_all, feat.contiguous(), group=self.group)
         dist.all_gather_into_tensor(cond_all, cond.contiguous(), group=self.group)
         return feat_all, cond_all
+
+    def allgather_stats(self, part):
+        """[2,H] fp32 statistics partial of every rank stacked in rank order -> [world,2,H]."""
+        out = torch.empty((self.world_size * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype,
+                          device=part.device)  # the flat "concatenate along dim 0" form every backend takes
+        dist.all_gather_into_tensor(out, part.contiguous(), group=self.group)
+        return out.view((self.world_size,) + tuple(part.shape))
 
     def allreduce_scalars(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -299,7 +299,12 @@ class Trainer:
         pass
 
     def on_iteration(self, batch_data):
-        """trainer.py:305-323.  (The frozen-BatchNorm tweak of :307-312 has no object here: use_bn is unbuilt.)"""
+        """trainer.py:305-323."""
+        if getattr(self.model, "freeze", False):  # :307-312: BatchNorm layers frozen by surgery stop tracking
+            for module in self.model.modules():
+                if isinstance(module, torch.nn.BatchNorm1d) and not module.weight.requires_grad:
+                    module.affine = False
+                    module.track_running_stats = False
         self.current_loss = loss = self.loss(batch_data)
         self.optimizer.zero_grad()
         loss.backward()

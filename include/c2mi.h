@@ -221,6 +221,44 @@ int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefact
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
                    int xin_dtype, int64_t ldxin, int apply_log, void* stream);
 
+/* ---- BatchNorm1d form of the layer tail (use_bn=True: modules.py:298-302, 405-413, 445-449, 557-566, 596-600;
+ * nn.BatchNorm1d(affine=True), eps 1e-5, momentum 0.1).  The statistics run over the batch, so the tail is cut at
+ * the points where a multi-GPU run exchanges them (SyncBN). ---- */
+
+/* floats of workspace for c2_bn_stats / c2_bn_bwd_reduce. */
+size_t c2_bn_ws(int64_t B, int64_t H);
+
+/* h_out[B,H] = sum_s Y[s] + bias + sum_j cond[b][j]*Wc[:,j] (as c2_epilogue_fwd) and, per column, the mean and the
+ * sum of squared deviations M2 of the B local rows: part_out[0][H] = mean, part_out[1][H] = M2. */
+int c2_bn_stats(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias, const int64_t* cond,
+                int C, const float* Wc, int64_t ldwc, int64_t B, int64_t H, float* h_out, float* part_out, float* ws,
+                void* stream);
+
+/* F.batch_norm + ReLU + dropout on h (overwritten by yhat = (h-mean)*rstd, kept for the backward).
+ * nparts > 0: batch statistics = Chan combination of `nparts` partials [nparts][2][H] (one per rank; partial i covers
+ *   rows [i*rows_per_part, min((i+1)*rows_per_part, total_rows))); update_running: running_mean / running_var
+ *   (unbiased variance) move by `momentum` and *num_batches_tracked += 1 (torch.nn.BatchNorm1d in train mode).
+ * nparts == 0: the running statistics normalise (eval mode).
+ * stats_out[0][H] = mean used, stats_out[1][H] = 1/sqrt(var+eps).  act = dropout(relu(yhat*gamma+beta)). */
+int c2_bn_fwd(float* h, const float* parts, int nparts, int64_t rows_per_part, int64_t total_rows, const float* gamma,
+              const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+              int update_running, float eps, const uint8_t* mask, float p_drop, int64_t B, int64_t H, void* act,
+              int act_dtype, int64_t ldact, float* stats_out, void* act_planes, void* stream);
+
+/* Backward, first half: dy[B,H] = (sum_s dA[s] + extra_scale*extra) through dropout and ReLU (fp32), and the column
+ * sums over the local rows sums_out[0][H] = sum dy, sums_out[1][H] = sum dy*yhat (= dbeta, dgamma, also written to
+ * those pointers when not NULL). */
+int c2_bn_bwd_reduce(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
+                     int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
+                     const float* yhat, const float* gamma, const float* beta, int64_t B, int64_t H, float* dy_out,
+                     float* sums_out, float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* Backward, second half: dh = gamma*rstd*(dy - sums[0]/n - yhat*sums[1]/n), n = total_rows (the sums all-reduced
+ * over ranks first); batch_stats == 0 (eval-mode statistics): dh = gamma*rstd*dy. */
+int c2_bn_bwd(const float* dy, const float* yhat, const float* sums, int64_t total_rows, int batch_stats,
+              const float* gamma, const float* stats, int64_t B, int64_t H, void* dh, int dh_dtype, int64_t lddh,
+              void* dh_planes, void* stream);
+
 /* Dropout keep-masks (nn.Dropout of modules.py:309-312,426-431,458-461,579-582,607-610) for all layers of a step in
  * one launch: out[i] = 1 with probability 1-p (Philox-4x32-10 keyed by seed, counter offset + i/16).  The stream of
  * random numbers differs from torch's generator by construction; parity tests inject recorded masks instead. */

@@ -579,6 +579,7 @@ def forward_backward(params, cfg: Cfg, batch, eps_noise, masks=None,
             new_buffers[nm + ".running_mean"], new_buffers[nm + ".running_var"] = bn["new_running"]
             new_buffers[nm + ".num_batches_tracked"] = np.asarray(buffers[nm + ".num_batches_tracked"]) + 1
     out["buffers"] = new_buffers
+    out["caches"] = caches  # per-block intermediates (a, yhat, pre, rstd, ...), for diagnostics
     if not want_grads:
         return out
     gr, gk, gm, gc = [dt.type(v) for v in gscale]
@@ -695,6 +696,8 @@ def init_params(cfg: Cfg, seed=0, dtype=np.float32):
     for k, shp in param_shapes(cfg).items():
         if k == "theta":
             out[k] = rng.standard_normal(shp).astype(dtype)
+        elif len(shp) == 1 and k.endswith("weight"):  # BatchNorm scale
+            out[k] = np.ones(shp, dtype)
         elif k.endswith("bias"):
             out[k] = (0.1 * rng.standard_normal(shp)).astype(dtype)
         else:

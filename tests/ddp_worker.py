@@ -1,6 +1,7 @@
 """Worker of tests/test_parallel_gpu.py: 2 ranks share cuda:0 (gloo backend, the box has one GPU); each runs the
 data-parallel step on its half of a global batch; rank 0 also runs the single-process step on the whole batch.
-The summed-gradient result must equal the single-process one (fp32 mode, 1e-4)."""
+The summed-gradient result must equal the single-process one (fp32 mode, 1e-4).  argv[1] == "bn": the BatchNorm1d
+variant, whose statistics are exchanged between the ranks (SyncBN); the running statistics must match too."""
 import os
 import sys
 
@@ -20,9 +21,10 @@ def main():
     from celligner2_amd.parallel import DataParallelStep
     from oracle import c2_oracle as orc
 
+    use_bn = len(sys.argv) > 1 and sys.argv[1] == "bn"
     G, hidden, L, C, P, B = 256, [48, 24], 8, 3, 4, 64
     cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=hidden, latent_dim=L, n_conditions=C, n_predictors=P,
-                  recon_loss="nb", use_mmd=True, beta=20.0)
+                  recon_loss="nb", use_mmd=True, beta=20.0, use_bn=use_bn)
     rng = np.random.default_rng(0)
     params = orc.init_params(cfg, 0, np.float32)
     x = rng.poisson(rng.uniform(0.5, 2, (B, 1)) * np.exp(rng.normal(1, 1, (1, G)))).astype(np.float32)
@@ -35,9 +37,9 @@ def main():
     eps = rng.standard_normal((B, L)).astype(np.float32)
 
     def build():
-        m = Celligner2(G, hidden, L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=20.0,
+        m = Celligner2(G, hidden, L, 0.0, False, "nb", use_bn, conditions=["a", "b", "c"], use_mmd=True, beta=20.0,
                        predictors=list("wxyz"))
-        m.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+        m.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=False)  # BN buffers: defaults
         return m.cuda().train()
 
     def run(m, sl):
@@ -46,9 +48,10 @@ def main():
         (r + 1e-3 * k + mm + ce).backward()
         return np.array([r.item(), k.item(), mm.item(), ce.item()]), {n: p.grad.clone() for n, p in m.named_parameters()}
 
-    ref_l = ref_g = None
+    ref_l = ref_g = ref_m = None
     if rank == 0:
-        ref_l, ref_g = run(build(), slice(0, B))
+        ref_m = build()
+        ref_l, ref_g = run(ref_m, slice(0, B))
     m = build()
     comm = DataParallelStep()
     comm.attach_model(m)
@@ -58,8 +61,16 @@ def main():
     ok = True
     if rank == 0:
         ok = bool(np.allclose(losses, ref_l, rtol=1e-4, atol=1e-5))
+        for n, b in ref_m.named_buffers():  # SyncBN: every rank holds the running statistics of the global batch
+            err = (dict(m.named_buffers())[n].double() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-30)
+            if err > 1e-5:
+                ok = False
+                print("MISMATCH buffer", n, err)
         for n in ref_g:
-            err = (grads[n] - ref_g[n]).abs().max().item() / max(ref_g[n].abs().max().item(), 1e-30)
+            den = ref_g[n].abs().max().item()
+            if use_bn and n.endswith(".bias") and n[:-4] + "weight" in ref_g:  # cancelling batch sums (gu.grad_err)
+                den = max(den, ref_g[n[:-4] + "weight"].abs().max().item())
+            err = (grads[n] - ref_g[n]).abs().max().item() / max(den, 1e-30)
             if err > 1e-4:
                 ok = False
                 print("MISMATCH", n, err)

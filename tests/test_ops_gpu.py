@@ -146,12 +146,10 @@ def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
         assert torch.equal(pl, ops.split_bf16(act))
     tol = 1e-4 if act_dtype == torch.float32 else 1e-2
     assert rel(act, out64) < tol
-    assert rel(yhat, cache[2]) < 1e-4
+    assert rel(yhat, cache["yhat"]) < 1e-4
     # backward: dout = sum of 2 slabs + 0.25*extra
     dtot = dout.sum(0).astype(np.float64) + 0.25 * extra
-    _, dW, db, dWc = orc._block_bwd(dtot, cache, np.eye(H), True, C > 0, need_da=False)
-    # dh = dW of an identity-weight block with a = h_in ... recover dh directly:
-    a_, cond_, yh, rs, mk, p_, ln_ = cache
+    yh, rs, mk = cache["yhat"], cache["rstd"], cache["mask"]
     d = dtot * (mk / (1 - p) if mk is not None else 1.0) * (yh > 0)
     dh64 = (d - d.mean(1, keepdims=True) - yh * (d * yh).mean(1, keepdims=True)) * rs if use_ln else d
     dh = torch.empty(B, H, device=DEV, dtype=act_dtype)
@@ -170,6 +168,114 @@ def test_epilogue_fwd_bwd(H, C, p, use_ln, act_dtype):
     assert rel(dbt, dh_np.sum(0)) < 1e-5
     if C:
         assert rel(dwct, dh_np.T @ cond[:, :C]) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,C,p", [(37, 64, 3, 0.0), (200, 1024, 2, 0.1), (65, 50, 0, 0.05), (1000, 512, 3, 0.0),
+                                      (33, 1500, 2, 0.0)])
+@pytest.mark.parametrize("act_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nrank", [1, 2])
+def test_batchnorm_tail(B, H, C, p, act_dtype, nrank):
+    """BatchNorm1d tail (c2_bn_stats / c2_bn_fwd / c2_bn_bwd_reduce / c2_bn_bwd) vs the oracle's block functions;
+    nrank = 2 runs it the way two data-parallel ranks do (row halves, partials stacked, sums added) and must give
+    the statistics and gradients of the whole batch.  Ragged row blocks, scalar path (H = 50), slabs, extra."""
+    ops = _ops()
+    rng = np.random.default_rng(B + H + C)
+    ns = 2
+    y = (rng.standard_normal((ns, B, H)) * 2 + 0.7).astype(np.float32)
+    bias = rng.standard_normal(H).astype(np.float32)
+    cond = np.zeros((B, max(C, 1)), np.int64)
+    cond[np.arange(B), rng.integers(0, max(C, 1), B)] = 1
+    cond[0, :] = 1
+    wc = rng.standard_normal((H, max(C, 1))).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(H)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(H)).astype(np.float32)
+    rm0 = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    rv0 = (1 + 0.3 * rng.uniform(size=H)).astype(np.float32)
+    mask = (rng.uniform(size=(B, H)) > p).astype(np.uint8) if p > 0 else None
+    dout = rng.standard_normal((2, B, H)).astype(np.float32)
+    extra = rng.standard_normal((B, H)).astype(np.float32)
+    f8 = lambda v: v.astype(np.float64)  # noqa: E731
+    bn = dict(weight=f8(gamma), bias=f8(beta), running_mean=f8(rm0), running_var=f8(rv0), batch_stats=True, track=True)
+    out64, cache = orc._block_fwd(f8(y.sum(0)), np.eye(H), f8(bias), f8(cond[:, :C]) if C else None,
+                                  f8(wc[:, :C]) if C else None, f8(mask) if mask is not None else None, p, True, bn)
+    dtot = f8(dout.sum(0)) + 0.25 * extra
+    da64, _, _, _, dgam64, dbet64 = orc._block_bwd(dtot, cache, np.eye(H), True, C > 0)  # identity weight: da = dh
+    if nrank == 2 and B % 2:
+        pytest.skip("ranks hold equal shares")
+    cuts = [0, B] if nrank == 1 else [0, B // 2, B]
+    Bs = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+    rm = [T(rm0.copy()) for _ in Bs]
+    rv = [T(rv0.copy()) for _ in Bs]
+    nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in Bs]
+    hs, parts, acts, stats, pls = [], [], [], [], []
+    want_pl = act_dtype == torch.float32 and H % 4 == 0
+    for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        n = b - a
+        h = torch.empty(n, H, device=DEV)
+        part = torch.empty(2, H, device=DEV)
+        ops.bn_stats(T(y[:, a:b].copy()), T(bias), T(cond[a:b, :C].copy()) if C else None,
+                     T(wc[:, :C].copy()) if C else None, h, part, torch.empty(ops.bn_ws(n, H), device=DEV))
+        hs.append(h)
+        parts.append(part)
+    allparts = torch.stack(parts).contiguous()
+    for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        n = b - a
+        act = torch.empty(n, H, device=DEV, dtype=act_dtype)
+        st = torch.empty(2, H, device=DEV)
+        pl = torch.zeros(2, n, H, device=DEV, dtype=torch.bfloat16) if want_pl else None
+        ops.bn_fwd(hs[r], allparts, Bs[0], B, T(gamma), T(beta), rm[r], rv[r], nbt[r], 0.1, True,
+                   T(mask[a:b].copy()) if mask is not None else None, p, act, st, planes=pl)
+        if want_pl:
+            assert torch.equal(pl, ops.split_bf16(act))
+        acts.append(act)
+        stats.append(st)
+        assert nbt[r].item() == 1
+        assert rel(rm[r], bn["new_running"][0]) < 1e-5 and rel(rv[r], bn["new_running"][1]) < 1e-5
+    tol = 1e-4 if act_dtype == torch.float32 else 1e-2
+    assert rel(torch.cat(acts).float(), out64) < tol
+    assert rel(torch.cat(hs), cache["yhat"]) < 1e-4
+    # backward
+    dys, sums, dgs, dbs = [], [], [], []
+    for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        n = b - a
+        dy = torch.empty(n, H, device=DEV)
+        sm = torch.empty(2, H, device=DEV)
+        dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+        ops.bn_bwd_reduce(T(dout[:, a:b].copy()), T(mask[a:b].copy()) if mask is not None else None, p, hs[r], T(gamma),
+                          T(beta), dy, sm, dg, db, torch.empty(ops.bn_ws(n, H), device=DEV), extra=T(extra[a:b].copy()),
+                          extra_scale=T(np.array([0.25], np.float32)))
+        dys.append(dy), sums.append(sm), dgs.append(dg), dbs.append(db)
+    tot = torch.stack(sums).sum(0)  # the all-reduce
+    assert rel(torch.stack(dgs).sum(0), dgam64) < 1e-4 and rel(torch.stack(dbs).sum(0), dbet64) < 1e-4
+    dhs = []
+    for r, n in enumerate(Bs):
+        dh = torch.empty(n, H, device=DEV, dtype=act_dtype)
+        pl = torch.zeros(2, n, H, device=DEV, dtype=torch.bfloat16) if want_pl else None
+        ops.bn_bwd(dys[r], hs[r], tot, B, True, T(gamma), stats[r], dh, planes=pl)
+        if want_pl:
+            assert torch.equal(pl, ops.split_bf16(dh))
+        dhs.append(dh)
+    assert rel(torch.cat(dhs).float(), da64) < (2e-4 if act_dtype == torch.float32 else 1e-2)
+    # eval mode: the running statistics normalise, nothing moves; backward without the mean terms
+    bn_e = dict(weight=f8(gamma), bias=f8(beta), running_mean=f8(rm0), running_var=f8(rv0), batch_stats=False)
+    out_e, cache_e = orc._block_fwd(f8(y.sum(0)), np.eye(H), f8(bias), f8(cond[:, :C]) if C else None,
+                                    f8(wc[:, :C]) if C else None, None, 0.0, True, bn_e)
+    da_e = orc._block_bwd(dtot, cache_e, np.eye(H), True, C > 0)[0]
+    h = torch.empty(B, H, device=DEV)
+    part = torch.empty(2, H, device=DEV)
+    ws = torch.empty(ops.bn_ws(B, H), device=DEV)
+    ops.bn_stats(T(y), T(bias), T(cond[:, :C].copy()) if C else None, T(wc[:, :C].copy()) if C else None, h, part, ws)
+    rme, rve = T(rm0.copy()), T(rv0.copy())
+    act = torch.empty(B, H, device=DEV, dtype=act_dtype)
+    st = torch.empty(2, H, device=DEV)
+    ops.bn_fwd(h, None, B, B, T(gamma), T(beta), rme, rve, nbt[0], 0.1, False, None, 0.0, act, st)
+    assert rel(act.float(), out_e) < tol and torch.equal(rme, T(rm0)) and nbt[0].item() == 1
+    dy, sm = torch.empty(B, H, device=DEV), torch.empty(2, H, device=DEV)
+    ops.bn_bwd_reduce(T(dout), None, 0.0, h, T(gamma), T(beta), dy, sm, None, None, ws, extra=T(extra),
+                      extra_scale=T(np.array([0.25], np.float32)))
+    dh = torch.empty(B, H, device=DEV, dtype=act_dtype)
+    ops.bn_bwd(dy, h, sm, B, False, T(gamma), st, dh)
+    assert rel(dh.float(), da_e) < (2e-4 if act_dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("B,H,C", [(1000, 515, 11), (300, 19000, 0), (129, 77, 5), (4096, 1024, 3)])

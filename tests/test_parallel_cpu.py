@@ -29,6 +29,18 @@ def _worker(rank, world, port, out):
     cond = torch.full((3, 2), rank, dtype=torch.int64)
     fa, ca = comm.allgather_rows(feat, cond)
     assert fa[:3].eq(0).all() and fa[3:].eq(1).all() and ca[3:].eq(1).all()
+    # SyncBN: per-rank (mean, M2) partials gathered in rank order combine (Chan) to the statistics of all rows
+    rows = np.random.default_rng(5).standard_normal((10, 4)) * 3 + 1
+    lo_, hi_ = comm.shard(10)
+    mine_ = rows[lo_:hi_]
+    part = torch.tensor(np.stack([mine_.mean(0), ((mine_ - mine_.mean(0)) ** 2).sum(0)]))
+    allp = comm.allgather_stats(part).numpy()
+    assert allp.shape == (2, 2, 4) and np.allclose(allp[rank], part.numpy())
+    n0, n1 = 5, 5
+    delta = allp[1, 0] - allp[0, 0]
+    mean = allp[0, 0] + delta * n1 / (n0 + n1)
+    m2 = allp[0, 1] + allp[1, 1] + delta ** 2 * n0 * n1 / (n0 + n1)
+    assert np.allclose(mean, rows.mean(0)) and np.allclose(m2 / 10, rows.var(0))
     # bucket all-reduce = SUM
     g = torch.arange(6, dtype=torch.float32) * (rank + 1)
     comm.allreduce_bucket_async(g)

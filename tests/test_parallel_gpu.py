@@ -9,9 +9,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_equal_single_process():
+@pytest.mark.parametrize("variant", ["ln", "bn"])
+def test_two_ranks_equal_single_process(variant):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "tests", "ddp_worker.py")]
+           "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
