@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libc2mi.so")
+LIB_PATH = os.environ.get("C2MI_LIB") or os.path.join(_HERE, "lib", "libc2mi.so")  # C2MI_LIB: ablation builds
 
 F32, BF16, F32X3, BF16X3P = 0, 1, 2, 3
 MMD_MAX_PARTS = 64

@@ -28,11 +28,15 @@
 namespace c2 {
 namespace wide {
 
-// Ablation builds only (-DC2_GEMM_DBG=1: no DMA after nothing, 2: no MFMA, 3: neither); 0 in the product.
+// Ablation builds only (-DC2_GEMM_DBG=1: no DMA, 2: no MFMA, 4 / 8: no A / B DMA in the steady loop); 0 in the product.
 #ifndef C2_GEMM_DBG
 #define C2_GEMM_DBG 0
 #endif
 constexpr int dbg = C2_GEMM_DBG;
+
+#if C2_GEMM_DBG & 16
+__device__ unsigned long long g_clk[4];  // shader-clock cycles and 100 MHz ticks of block 0 (clock probe)
+#endif
 
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;  // tiles along M that share a panel of B
@@ -141,7 +145,8 @@ __device__ __forceinline__ void mma_step(const bf16x8 (&fa)[MI], const bf16x8 (&
 // One K-tile: the fragments of step ks+1 are read while step ks is multiplied (two register sets).
 // `piece(p)`, p = 0..3, issues a quarter of the iteration's LDS-DMA (two instructions) in front of each MFMA group,
 // so that a wave never sits in a long run of VMEM issue while the memory pipeline is full (measured at NW = 8:
-// 980 TF; one instruction per 4 MFMAs 920; all eight up front 840).
+// 980 TF; one instruction per 4 MFMAs 920; all eight up front 840; all eight after the last MFMA group, where the
+// wave would otherwise idle at the barrier, 830; in the second half of the tile 860).
 template <bool A_RC, bool B_RC, int BX, int MI, typename F>
 __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, int wm, int wn, int lane,
                                              f32x16 (&acc)[MI][2], F&& piece) {
@@ -182,6 +187,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
+#if C2_GEMM_DBG & 16
+    const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
+#endif
 
     // ---- workgroup -> (split, tile) with the blocks of one XCD on a compact panel
     int wg;
@@ -292,20 +300,33 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     int sa = 0;  // slot of A_T; B_T is in the next one
     auto slot_of = [&](int d) { return sa + d >= NSLOT ? sa + d - NSLOT : sa + d; };
     int T = 0;
+#if C2_GEMM_DBG & 16
+    unsigned long long wait_clk = 0, bar_clk = 0;
+#endif
     for (; T < nfast; ++T) {
         // loads 2T and 2T+1 must have landed; the 2D-3 newer ones stay in flight
+#if C2_GEMM_DBG & 16
+        const unsigned long long w0 = clock64();
+#endif
         wait_loads(2 * D - 3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if C2_GEMM_DBG & 16
+        const unsigned long long w1 = clock64();
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if C2_GEMM_DBG & 16
+        wait_clk += w1 - w0;
+        bar_clk += clock64() - w1;
+#endif
         char* d3 = smem + slot_of(2 * D - 1) * TILE_BYTES;  // the slots tile T-1 occupied: every wave is past
         char* d4 = smem + slot_of(2 * D) * TILE_BYTES;      // its reads of them
         auto piece = [&](int p) {
             if (dbg & 1) return;
-            if (p == 0) stage_dma<0, 2>(pB, vob, d3, wave);
-            if (p == 1) stage_dma<2, 4>(pB, vob, d3, wave);
-            if (p == 2) stage_dma<0, 2>(pA, voa, d4, wave);
-            if (p == 3) stage_dma<2, 4>(pA, voa, d4, wave);
+            if (p == 0 && !(dbg & 8)) stage_dma<0, 2>(pB, vob, d3, wave);
+            if (p == 1 && !(dbg & 8)) stage_dma<2, 4>(pB, vob, d3, wave);
+            if (p == 2 && !(dbg & 4)) stage_dma<0, 2>(pA, voa, d4, wave);
+            if (p == 3 && !(dbg & 4)) stage_dma<2, 4>(pA, voa, d4, wave);
         };
         if (!(dbg & 2)) {
             compute_tile<A_RC, B_RC, BX, MI>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc,
@@ -342,6 +363,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         sa = slot_of(2);
     }
 
+#if C2_GEMM_DBG & 16
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_clk[0] = clock64() - clk0;
+        g_clk[1] = wall_clock64() - rt0;
+        g_clk[2] = wait_clk;
+        g_clk[3] = bar_clk;
+    }
+#endif
     // ---- epilogue: C = alpha * acc + bias, transposed through LDS for 16-byte-per-lane stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
@@ -393,6 +422,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
 }
 
 }  // namespace wide
+
+#if C2_GEMM_DBG & 16
+extern "C" int c2_dbg_clk(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wide::g_clk), 32);
+}
+#endif
 
 // 0 = not taken by this file; 256 / 128 = block-tile edge.
 int wide_tile(int dtype, const GemmArgs& a) {

@@ -34,7 +34,13 @@ def main():
     for name, fn in cases.items():
         if which != "all" and which not in name: continue
         us = bench(fn, reps)
-        print(f"{name:50s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s")
+        extra = ""
+        if hasattr(ops.lib, "c2_dbg_clk"):  # clock-probe build (-DC2_GEMM_DBG=16): shader clock during the main loop
+            import ctypes
+            buf = (ctypes.c_ulonglong * 4)()
+            ops.lib.c2_dbg_clk(buf)
+            extra = f"  block0 loop: {buf[0]} clk in {buf[1] / 100:.1f} us = {buf[0] / max(buf[1], 1) * 100:.0f} MHz; wave0 wait {buf[2]} barrier {buf[3]} clk"
+        print(f"{name:50s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s{extra}")
 
 if __name__ == "__main__":
     main()
