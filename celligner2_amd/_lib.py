@@ -65,7 +65,11 @@ _SIGS = {
     "c2_mmd_fwd_bwd": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp, vp]),
     "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f64, f64, f64, f64, f64, f64, i64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
-    "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
+                             vp]),
+    "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),
+    "c2_scale4": (i32, [vp, f32, f32, f32, f32, vp, vp]),
+    "c2_scale": (i32, [vp, vp, vp, i64, vp]),
     "c2_axpy": (i32, [vp, vp, vp, i64, vp]),
     "c2_dropout_masks": (i32, [vp, i64, f32, C.c_uint64, C.c_uint64, vp]),
 }

@@ -535,7 +535,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const int64_t* __restrict__ cond, const int64_t* __restrict__ classes, int64_t G, int C, int P,
     const int64_t* __restrict__ idx, float* __restrict__ x_out, uint8_t* __restrict__ goodloc_out,
     float* __restrict__ sf_out, int64_t* __restrict__ cond_out, int64_t* __restrict__ classes_out,
-    TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin) {
+    TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin,
+    const float* __restrict__ rowconst, float* __restrict__ rowconst_out) {
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
     const float* xs = X + src * G;
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         }
     }
     if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
+    if (threadIdx.x == 0 && rowconst) rowconst_out[r] = rowconst[src];
     if (cond)
         for (int j = threadIdx.x; j < C; j += 256) cond_out[r * C + j] = cond[src * C + j];
     if (classes)
@@ -625,6 +627,28 @@ __global__ void axpy_kernel(const float* __restrict__ x, const float* __restrict
     const float a = a_dev ? *a_dev : 1.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] += a * x[i];
+}
+// out6 = (l0, l1, l2, l3, sum_i w_i*l_i, l0+l1+l2): the step's loss vector in one launch
+__global__ void combine_losses_kernel(const float* __restrict__ l, float w0, float w1, float w2, float w3,
+                                      float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const float a = l[0], b = l[1], c = l[2], d = l[3];
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+        out[4] = ((w0 * a + w1 * b) + w2 * c) + w3 * d;
+        out[5] = (a + b) + c;
+    }
+}
+__global__ void scale4_kernel(const float* __restrict__ g, float w0, float w1, float w2, float w3,
+                              float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const float s = g ? g[0] : 1.f;
+        out[0] = w0 * s; out[1] = w1 * s; out[2] = w2 * s; out[3] = w3 * s;
+    }
+}
+__global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ a_dev, float* __restrict__ y,
+                             int64_t n) {
+    const float a = *a_dev;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a * x[i];
 }
 __global__ void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -844,8 +868,9 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
                               const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
                               float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
                               int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
-                              void* stream) {
+                              const float* rowconst, float* rowconst_out, void* stream) {
     C2_CHECK(X && idx, "null pointer");
+    C2_CHECK(!rowconst || rowconst_out, "rowconst_out missing");
     C2_CHECK(x_out || xin_out, "nothing to write: x_out and xin_out are both NULL");
     C2_CHECK(!sizefactor || sf_out, "sf_out missing");
     C2_CHECK(!cond || cond_out, "cond_out missing");
@@ -859,11 +884,11 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
     if (xin_out && xin_dtype == C2_BF16)
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin);
+                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin);
+                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out);
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -884,6 +909,29 @@ extern "C" int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, 
     C2_CHECK(x && y && n >= 0, "bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a_dev, y, n);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float w3, float* out6,
+                                 void* stream) {
+    C2_CHECK(losses4 && out6, "null pointer");
+    hipLaunchKernelGGL(combine_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses4, w0, w1, w2, w3, out6);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float* out4, void* stream) {
+    C2_CHECK(out4, "null pointer");
+    hipLaunchKernelGGL(scale4_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_dev, w0, w1, w2, w3, out4);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_scale(const float* x, const float* a_dev, float* y, int64_t n, void* stream) {
+    C2_CHECK(x && a_dev && y, "null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a_dev, y, n);
     C2_LAUNCH_CHECK();
     return 0;
 }

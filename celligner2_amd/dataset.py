@@ -162,11 +162,13 @@ class DeviceDataset:
         xin = None
         if xin_dtype is not None:
             xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
+        rc = rc_o = None
+        if nb_const:
+            rc, rc_o = self.nb_row_const, get("lgx1", (n,), torch.float32)
+            out["lgx1"] = rc_o
         ops.gather_rows(self.data, self.goodloc, self.size_factors, self.conditions if cond_o is not None else None,
                         self.predictors if cls_o is not None else None, idx, out.get("x"), out.get("goodloc"),
-                        out["sizefactor"], cond_o, cls_o, xin, apply_log)
-        if nb_const:
-            out["lgx1"] = torch.index_select(self.nb_row_const, 0, idx, out=get("lgx1", (n,), torch.float32))
+                        out["sizefactor"], cond_o, cls_o, xin, apply_log, rowconst=rc, rowconst_out=rc_o)
         return out
 
 

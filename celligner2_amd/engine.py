@@ -416,10 +416,10 @@ class StepEngine:
         inv_B = 1.0 / Bn
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
         self._aplanes = {}
-        losses = self.buf("losses", (4,))
-        losses.zero_()
-        status = self.buf("status", (2,), torch.int32)
-        status.zero_()
+        ls = self.buf("losses+status", (8,))  # one zero-fill: 4 fp32 losses, 2 int32 status words
+        ls.zero_()
+        losses = self._ws["losses"] = ls[0:4]
+        status = self._ws["status"] = ls[4:6].view(torch.int32)
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
         pre = batch.get("xin")  # already produced by the device-resident gather
@@ -562,9 +562,7 @@ class StepEngine:
                 ops.bias_cond_grad(dpi, None, self.gbuf(h2b), None, ws, alpha=gr)
             self._dgrad(dpi, h2w, dd[ns1:], alpha=gr)
         if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
-            gt = self.gbuf("theta")
-            gt.zero_()
-            ops.axpy(self._ws["dtheta.unit"], gr, gt)
+            ops.scale(self._ws["dtheta.unit"], gr, self.gbuf("theta"))
         self._build_arena()
         self._reduce_bucket(0)  # overlaps everything below
         # ---- decoder hidden blocks, then the first block (mmd_on='y' enters at its output)

@@ -151,6 +151,39 @@ class _StepFn(torch.autograd.Function):
             (grads[n].clone() if (p.requires_grad and n in grads) else None) for n, p in zip(names, params))
 
 
+class _StepTotalFn(torch.autograd.Function):
+    """The weighted total of the four losses as one autograd node (what the trainer differentiates,
+    semisupervised.py:63-66): returns (total, loss vector); the vector (recon, kl, mmd, ce, total, recon+kl+mmd) is
+    for logging and carries no gradient.  One launch builds it, one launch builds the backward seed."""
+
+    @staticmethod
+    def forward(ctx, model, batch, eps, masks, weights, *params):
+        eng = model._engine()
+        losses = eng.forward(batch, eps, masks, train=model.training, save=True)
+        out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
+        ops.combine_losses(losses, weights, out6)
+        ctx.model, ctx.weights = model, weights
+        total = out6[4]
+        ctx.mark_non_differentiable(out6)
+        return total.view(()), out6
+
+    @staticmethod
+    def backward(ctx, gtotal, _g6):
+        model = ctx.model
+        eng = model._engine()
+        g = ops.scale4(gtotal.float().contiguous() if gtotal is not None else None, ctx.weights, eng.buf("gseed", (4,)))
+        grads = eng.backward(g)
+        names, params = model._param_names, model._param_list
+        head = (None, None, None, None, None)
+        if all(p.grad is None for p in params):
+            for n, p in zip(names, params):
+                if p.requires_grad and n in grads:
+                    p.grad = grads[n]
+            return head + tuple(None for _ in params)
+        return head + tuple((grads[n].clone() if (p.requires_grad and n in grads) else None)
+                            for n, p in zip(names, params))
+
+
 class Celligner2(nn.Module):
     def __init__(
         self,
@@ -384,12 +417,30 @@ class Celligner2(nn.Module):
             bt["lgx1"] = lgx1.float().contiguous()
         eps, masks = self._draw_noise(B, classes is not None, dev)
         params = [p for _, p in self.named_parameters()]
+        weights = self.__dict__.pop("_total_weights", None)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._engine()
+            if weights is not None:
+                return _StepTotalFn.apply(self, bt, eps, masks, weights, *params)
             return _StepFn.apply(self, bt, eps, masks, *params)
         eng = self._engine()
+        if weights is not None:
+            out6 = torch.empty(6, dtype=torch.float32, device=dev)
+            ops.combine_losses(eng.forward(bt, eps, masks, train=self.training, save=False), weights, out6)
+            return out6[4], out6
         losses = eng.forward(bt, eps, masks, train=self.training, save=False).clone()
         return losses[0], losses[1], losses[2], losses[3]
+
+    def forward_total(self, weights, **batch):
+        """forward + the weighted total in one autograd node: returns (total, v) with total = sum_i weights[i]*loss_i
+        (differentiable) and v = [recon, kl, mmd, ce, total, recon+kl+mmd] (fp32 [6], no gradient).  What the
+        trainer's `loss = recon + alpha*kl + mmd + ce` (semisupervised.py:63-66) needs, without the dozen
+        single-element torch kernels that expression and its autograd graph launch."""
+        self.__dict__["_total_weights"] = tuple(float(w) for w in weights)
+        try:
+            return self(**batch)
+        finally:
+            self.__dict__.pop("_total_weights", None)
 
     def sampling(self, mu, log_var):
         """othermodels/base/_base.py:464-480."""

@@ -448,7 +448,7 @@ def cast_bf16(src, dst):
 
 
 def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, sf_out, cond_out, classes_out, xin_out,
-                apply_log):
+                apply_log, rowconst=None, rowconst_out=None):
     L.require_gpu(X, idx, x_out)
     G = X.shape[1]
     n = idx.numel()
@@ -458,7 +458,33 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
     check(lib.c2_gather_rows(ptr(X), ptr(goodloc), ptr(sizefactor), ptr(cond), ptr(classes), G, C, P, ptr(idx), n,
                              ptr(x_out), ptr(goodloc_out), ptr(sf_out), ptr(cond_out), ptr(classes_out), ptr(xin_out),
                              dt_code(xin_out.dtype) if xin_out is not None else 0,
-                             xin_out.stride(0) if xin_out is not None else 0, int(apply_log), stream()))
+                             xin_out.stride(0) if xin_out is not None else 0, int(apply_log), ptr(rowconst),
+                             ptr(rowconst_out), stream()))
+
+
+def combine_losses(losses4, weights, out6):
+    """out6 = (recon, kl, mmd, ce, weighted total, recon + kl + mmd)."""
+    L.require_gpu(losses4, out6)
+    assert losses4.dtype == torch.float32 and losses4.numel() == 4 and out6.dtype == torch.float32 and out6.numel() == 6
+    w = [float(v) for v in weights]
+    check(lib.c2_combine_losses(ptr(losses4), w[0], w[1], w[2], w[3], ptr(out6), stream()))
+    return out6
+
+
+def scale4(g_dev, weights, out4):
+    """out4[i] = weights[i] * g (g: 0-d / 1-element fp32 device tensor, or None for 1)."""
+    L.require_gpu(out4)
+    assert out4.dtype == torch.float32 and out4.numel() == 4
+    if g_dev is not None:
+        assert g_dev.dtype == torch.float32 and g_dev.numel() == 1 and g_dev.is_cuda
+    w = [float(v) for v in weights]
+    check(lib.c2_scale4(ptr(g_dev), w[0], w[1], w[2], w[3], ptr(out4), stream()))
+    return out4
+
+
+def scale(x, a_dev, y):
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib.c2_scale(ptr(x), ptr(a_dev), ptr(y), x.numel(), stream()))
 
 
 def axpy(x, a_dev, y):

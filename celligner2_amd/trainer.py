@@ -307,7 +307,10 @@ class Trainer:
                     module.track_running_stats = False
         self.current_loss = loss = self.loss(batch_data)
         self.optimizer.zero_grad()
-        loss.backward()
+        one = self.__dict__.get("_one")
+        if one is None or one.device != loss.device:
+            one = self.__dict__["_one"] = torch.ones((), device=loss.device)
+        loss.backward(gradient=one)  # a persistent seed: autograd does not launch a fill for it
         # clip_grad_value_ (trainer.py:320-321) is folded into the fused Adam kernel (clip_value hyper-parameter)
         self.optimizer.step()
 
@@ -354,15 +357,16 @@ class Celligner2Trainer(Trainer):
 
     def loss(self, total_batch=None):
         """semisupervised.py:63-74."""
-        recon_loss, kl_loss, mmd_loss, class_ce_loss = self.model(**total_batch)
-        loss = recon_loss + self.calc_alpha_coeff() * kl_loss + mmd_loss + class_ce_loss
+        # loss = recon + alpha*kl + mmd + ce (:66) and unweighted_loss = recon + kl + mmd (:69), built with the four
+        # losses by one kernel (Celligner2.forward_total) instead of single-element torch ops
+        loss, v = self.model.forward_total((1.0, self.calc_alpha_coeff(), 1.0, 1.0), **total_batch)
         if self.log_sync == "step":
-            conv = lambda t: t.item()  # noqa: E731
+            vals = v.tolist()
         else:
-            conv = lambda t: t.detach()  # noqa: E731
-        r, k, m, c = conv(recon_loss), conv(kl_loss), conv(mmd_loss), conv(class_ce_loss)
-        self.iter_logs["loss"].append(conv(loss))
-        self.iter_logs["unweighted_loss"].append(r + k + m)
+            vals = list(v.detach().unbind(0))  # views: no kernel
+        r, k, m, c = vals[0], vals[1], vals[2], vals[3]
+        self.iter_logs["loss"].append(vals[4])
+        self.iter_logs["unweighted_loss"].append(vals[5])
         self.iter_logs["recon_loss"].append(r)
         self.iter_logs["kl_loss"].append(k)
         self.iter_logs["class_ce_loss"].append(c)

@@ -215,11 +215,13 @@ int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * dataset/celligner2/anndata.py:89-105, trainers/celligner2/_utils.py:188-225, trainer.py:274-275):
  * rows idx[0..n) of x/goodloc/sizefactor/cond/classes are gathered into dense batch tensors; xin
  * (= log(1+x) or x, dtype xin_dtype) is produced in the same pass (may be NULL).  x_out and goodloc_out may be
- * NULL when the consumer reads the resident rows itself (c2_recon_nb_fwd_bwd's row_index). */
+ * NULL when the consumer reads the resident rows itself (c2_recon_nb_fwd_bwd's row_index).  rowconst (may be NULL):
+ * a second per-row fp32 scalar gathered like sizefactor (the dataset's c2_nb_row_const vector). */
 int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
                    const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n, float* x_out,
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
-                   int xin_dtype, int64_t ldxin, int apply_log, void* stream);
+                   int xin_dtype, int64_t ldxin, int apply_log, const float* rowconst, float* rowconst_out,
+                   void* stream);
 
 /* ---- BatchNorm1d form of the layer tail (use_bn=True: modules.py:298-302, 405-413, 445-449, 557-566, 596-600;
  * nn.BatchNorm1d(affine=True), eps 1e-5, momentum 0.1).  The statistics run over the batch, so the tail is cut at
@@ -263,6 +265,17 @@ int c2_bn_bwd(const float* dy, const float* yhat, const float* sums, int64_t tot
  * one launch: out[i] = 1 with probability 1-p (Philox-4x32-10 keyed by seed, counter offset + i/16).  The stream of
  * random numbers differs from torch's generator by construction; parity tests inject recorded masks instead. */
 int c2_dropout_masks(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
+/* The step's loss vector in one launch (semisupervised.py:63-66 `loss = recon + alpha*kl + mmd + ce` and
+ * :69 `unweighted_loss`): out6 = (recon, kl, mmd, ce, w0*recon + w1*kl + w2*mmd + w3*ce, recon + kl + mmd). */
+int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float w3, float* out6, void* stream);
+
+/* Its backward seed: out4[i] = w_i * g (g = *g_dev, or 1 when g_dev is NULL) -- the upstream gradients of the four
+ * losses when the weighted total receives gradient g. */
+int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float* out4, void* stream);
+
+/* y[i] = a*x[i] (a = *a_dev), fp32. */
+int c2_scale(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
 
 /* y[i] = a*x[i] + y[i] (a = *a_dev), fp32; used to merge loss-branch gradients. */
 int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
