@@ -30,21 +30,33 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
     __shared__ int s_map[MAXP];
     __shared__ int s_cnt[MAXP];
     __shared__ int s_n, s_bad, s_nparts;
+    __shared__ float s_wt[MAXP * MAXP];
     const int tid = threadIdx.x;
     if (tid == 0) { s_n = 0; s_bad = 0; s_nparts = 0; }
     for (int i = tid; i < MAXP; i += 1024) s_cnt[i] = 0;
     __syncthreads();
     // keys: column 0 is the most significant bit -> numeric order == lexicographic row order
+    // (the first KREG keys of a thread also stay in registers: batches up to 8192 rows never re-read global memory)
+    constexpr int KREG = 8;
+    unsigned long long kreg[KREG];
     int bad = 0;
-    for (int64_t r = tid; r < B; r += 1024) {
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) kreg[i] = ~0ull;
+    auto make_key = [&](int64_t r) {
         unsigned long long k = 0;
         for (int j = 0; j < C; ++j) {
             const int64_t v = cond[r * C + j];
             bad |= (v != 0 && v != 1);
             k = (k << 1) | (unsigned long long)(v == 1);
         }
-        keys[r] = k;
+        return k;
+    };
+#pragma unroll
+    for (int q = 0; q < KREG; ++q) {  // independent iterations: the loads of all of a thread's rows are in flight together
+        const int64_t r = tid + 1024ll * q;
+        if (r < B) kreg[q] = make_key(r);
     }
+    for (int64_t r = tid + 1024ll * KREG; r < B; r += 1024) keys[r] = make_key(r);
     if (bad) s_bad = 1;
     __syncthreads();
     // unique keys ascending by repeated min-extraction
@@ -53,7 +65,12 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
     bool have_cur = false;
     for (int it = 0; it <= MAXP; ++it) {
         unsigned long long m = NONE;
-        for (int64_t r = tid; r < B; r += 1024) {
+#pragma unroll
+        for (int q = 0; q < KREG; ++q) {  // slots past the batch hold NONE, which never wins
+            const unsigned long long k = kreg[q];
+            if ((!have_cur || k > cur) && k < m) m = k;
+        }
+        for (int64_t r = tid + 1024ll * KREG; r < B; r += 1024) {
             const unsigned long long k = keys[r];
             if ((!have_cur || k > cur) && k < m) m = k;
         }
@@ -98,25 +115,39 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
         s_nparts = np;
     }
     __syncthreads();
-    for (int64_t r = tid; r < B; r += 1024) {
-        const unsigned long long k = keys[r];
-        int u = 0;
-        for (; u < n; ++u)
-            if (s_uniq[u] == k) break;
-        const int p = (u < n) ? s_map[u] : 0;
-        part_id[r] = p;
-        atomicAdd(&s_cnt[p], 1);
+    auto assign = [&](int64_t r, unsigned long long k) {
+        int p = -1;
+        if (r < B) {
+            int u = 0;
+            for (; u < n; ++u)
+                if (s_uniq[u] == k) break;
+            p = (u < n) ? s_map[u] : 0;
+            part_id[r] = p;
+        }
+        // one LDS atomic per wave and partition (a per-row atomic serialises 4096 adds on a handful of counters);
+        // every lane takes part in the ballots (uniform trip counts below)
+        for (int q = 0; q < s_nparts; ++q) {
+            const unsigned long long bal = __ballot(p == q);
+            if ((tid & 63) == 0 && bal) atomicAdd(&s_cnt[q], __popcll(bal));
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < KREG; ++q)
+        if (1024ll * q < B) assign(tid + 1024ll * q, kreg[q]);
+    for (int64_t base = 1024ll * KREG; base < B; base += 1024) {
+        const int64_t r = base + tid;
+        assign(r, r < B ? keys[r] : 0ull);
     }
-    for (int i = tid; i < MAXP * MAXP; i += 1024) wt[i] = 0.f;
+    for (int i = tid; i < MAXP * MAXP; i += 1024) s_wt[i] = 0.f;
     __syncthreads();
     if (tid == 0) {
         const int np = s_nparts;
-        auto add_pair = [&](int i, int j) {
+        auto add_pair = [&](int i, int j) {  // accumulated in LDS: a chain of global read-modify-writes costs ~1 us each
             const float ni = (float)s_cnt[i], nj = (float)s_cnt[j];
-            wt[i * MAXP + i] += 1.f / (ni * ni);
-            wt[j * MAXP + j] += 1.f / (nj * nj);
-            wt[i * MAXP + j] -= 1.f / (ni * nj);
-            wt[j * MAXP + i] -= 1.f / (ni * nj);
+            s_wt[i * MAXP + i] += 1.f / (ni * ni);
+            s_wt[j * MAXP + j] += 1.f / (nj * nj);
+            s_wt[i * MAXP + j] -= 1.f / (ni * nj);
+            s_wt[j * MAXP + i] -= 1.f / (ni * nj);
         };
         if (boundary >= 0) {  // losses.py:232-238
             for (int i = 0; i < boundary; ++i)
@@ -137,6 +168,8 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
         }
         if (s_bad) *status = 2;
     }
+    __syncthreads();
+    for (int i = tid; i < MAXP * MAXP; i += 1024) wt[i] = s_wt[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -163,6 +163,7 @@ class _StepTotalFn(torch.autograd.Function):
         out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
         ops.combine_losses(losses, weights, out6)
         ctx.model, ctx.weights = model, weights
+        ctx.set_materialize_grads(False)  # no zero-fill launch for the loss vector's (absent) gradient
         total = out6[4]
         ctx.mark_non_differentiable(out6)
         return total.view(()), out6

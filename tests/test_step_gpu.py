@@ -206,3 +206,78 @@ def test_bf16_step_midsize_vs_oracle(use_bn):
         assert np.linalg.norm(yh - ref["caches"][blk]["yhat"]) / np.linalg.norm(yh) < 1e-2, blk
     for n, b in m.named_buffers():
         assert gu.relerr(b.cpu().numpy(), ref["buffers"][n]) < 1e-2, n
+
+
+def test_forward_total_equals_combined_losses():
+    """Celligner2.forward_total (one autograd node for recon + alpha*kl + mmd + ce, what the trainer differentiates)
+    gives the losses and gradients of the four-output forward combined with torch ops."""
+    z, meta = gu.load("nb_mmd_z_dropout")
+    batch_np = gu.group(z, "batch/")
+    masks = {k: torch.tensor(v).to(DEV) for k, v in gu.group(z, "s0/mask/").items()}
+    alpha = 0.37
+    grads = []
+    vals = []
+    for mode in ("four", "total"):
+        model = build_model(meta, z, "fp32")
+        model._forced_noise = dict(eps=torch.tensor(z["s0/eps"]).to(DEV), masks=masks)
+        batch = {k: torch.tensor(v).to(DEV) for k, v in batch_np.items()}
+        if mode == "four":
+            r, k, m, c = model(**batch)
+            loss = r + alpha * k + m + c
+            vals.append([r.item(), k.item(), m.item(), c.item(), loss.item(), (r + k + m).item()])
+            loss.backward()
+        else:
+            loss, v = model.forward_total((1.0, alpha, 1.0, 1.0), **batch)
+            assert loss.dim() == 0 and not v.requires_grad
+            vals.append(v.tolist())
+            assert abs(loss.item() - v[4].item()) == 0.0
+            loss.backward(gradient=torch.ones((), device=DEV))
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert np.allclose(vals[0], vals[1], rtol=1e-6)
+    assert set(grads[0]) == set(grads[1])
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-6, atol=1e-9), n
+
+
+def test_surgery_query_model_step_vs_oracle():
+    """load_query_model (reference model + one new condition, surgery freeze) -> one training step: gradients of the
+    trainable tensors (theta, cond_L.weight, incl. the new columns) match the oracle on the expanded parameters,
+    every frozen tensor gets no gradient and does not move."""
+    from celligner2_amd import surgery
+    from celligner2_amd.model import Celligner2
+    from celligner2_amd.optim import FusedAdam
+    from oracle import c2_oracle as orc
+    torch.manual_seed(3)
+    G, hidden, L, B = 64, [24, 12], 5, 48
+    ref = Celligner2(G, hidden, L, 0.05, False, "nb", conditions=["a", "b", "c"], predictors=["p0", "p1", "p2"],
+                     use_mmd=True, beta=7.0)
+    q = surgery.load_query_model((ref, surgery.public_attributes(ref)), new_conditions=["d"], device=DEV)
+    q.train()
+    rng = np.random.default_rng(1)
+    C, P = 4, 3
+    x = rng.poisson(rng.uniform(0.5, 2.0, (B, 1)) * np.exp(rng.normal(1.0, 1.0, (1, G)))).astype(np.float32)
+    cond = np.zeros((B, C), np.int64)
+    cond[np.arange(B), rng.integers(0, C, B)] = 1
+    cond[:C] = np.eye(C, dtype=np.int64)
+    cls = np.zeros((B, P), np.int64)
+    cls[np.arange(B), rng.integers(0, P, B)] = 1
+    batch = dict(x=x, batch=cond, sizefactor=x.sum(1).astype(np.float32), goodloc=np.ones((B, G), bool), classes=cls)
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=hidden, latent_dim=L, n_conditions=C, n_predictors=P,
+                  recon_loss="nb", use_mmd=True, beta=7.0)
+    params = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in q.state_dict().items()}
+    out = orc.forward_backward(params, cfg, batch, eps.astype(np.float64), gscale=(1, 1e-3, 1, 1))
+    q._forced_noise = dict(eps=torch.tensor(eps).to(DEV), masks={})
+    before = {k: v.detach().clone() for k, v in q.state_dict().items()}
+    opt = FusedAdam([p for p in q.parameters() if p.requires_grad], lr=1e-3, eps=0.01, weight_decay=0.04)
+    r, k, m, c = q(**{k_: torch.tensor(v).to(DEV) for k_, v in batch.items()})
+    (r + 1e-3 * k + m + c).backward()
+    trainable = {"theta", "encoder.FC.L0.cond_L.weight", "decoder.FirstL.L0.cond_L.weight"}
+    for n, p in q.named_parameters():
+        if n in trainable:
+            assert gu.relerr(p.grad.cpu().numpy(), out["grads"][n]) < 1e-4, n
+        else:
+            assert p.grad is None, n
+    opt.step()
+    for n, v in q.state_dict().items():
+        assert torch.equal(v, before[n]) == (n not in trainable), n
