@@ -440,6 +440,55 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
         out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = s;
     }
 }
+// Bias only (no condition columns), 16-byte loads: block = 64 column groups (8 bf16 / 4 fp32 columns each) x 4 row
+// groups; a thread walks every 4th row of the chunk with 8 independent loads in flight.
+template <typename TI>
+__global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh, int64_t lddh, int64_t B, int H,
+                                                       float* __restrict__ ws /*[nchunk][H]*/) {
+    constexpr int W = 16 / sizeof(TI);  // columns per thread
+    __shared__ float red[4][64 * W];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cx) * W;
+    const int chunk = blockIdx.y;
+    const int64_t b0 = (int64_t)chunk * kBCG_RB, b1 = min(B, b0 + kBCG_RB);
+    float acc[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) acc[e] = 0.f;
+    if (col < H) {
+        auto add = [&](const u32x4& v) {
+            if constexpr (sizeof(TI) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __builtin_bit_cast(float, v[e] << 16);
+                    acc[2 * e + 1] += __builtin_bit_cast(float, v[e] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned w = v[e];  // (bit_cast straight from the vector element reads element 0: copy first)
+                    acc[e] += __builtin_bit_cast(float, w);
+                }
+            }
+        };
+        int64_t b = b0 + ry;
+        for (; b + 28 < b1; b += 32) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(dh + (b + 4 * u) * lddh + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(v[u]);
+        }
+        for (; b < b1; b += 4) add(*reinterpret_cast<const u32x4*>(dh + b * lddh + col));
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) red[ry][cx * W + e] = acc[e];
+    __syncthreads();
+    float* out = ws + (int64_t)chunk * H;
+    for (int i = threadIdx.x; i < 64 * W; i += 256) {
+        const int gc = blockIdx.x * 64 * W + i;
+        if (gc < H) out[gc] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
 __global__ __launch_bounds__(256) void bias_cond_stage2(const float* __restrict__ ws, int nchunk, int C, int H,
                                                         float* __restrict__ db, float* __restrict__ dWc, int64_t lddwc,
                                                         const float* __restrict__ alpha_dev) {
@@ -544,8 +593,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const bool copy_good = goodloc && goodloc_out;
     if (vec_ok) {
         const int64_t gv = G >> 2;
-        for (int64_t c = threadIdx.x; c < gv; c += 256) {
-            f32x4 v = reinterpret_cast<const f32x4*>(xs)[c];
+        auto emit = [&](int64_t c, const f32x4& v, unsigned gm) {
             if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
             if (xin_out) {
                 f32x4 t;
@@ -564,10 +612,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
                     for (int e = 0; e < 4; ++e) st_from_f32<TX>(dst + e, t[e]);
                 }
             }
-            if (copy_good)
-                reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] =
-                    reinterpret_cast<const unsigned int*>(goodloc + src * G)[c];
+            if (copy_good) reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] = gm;
+        };
+        const unsigned int* gs = copy_good ? reinterpret_cast<const unsigned int*>(goodloc + src * G) : nullptr;
+        int64_t c = threadIdx.x;
+        for (; c + 768 < gv; c += 1024) {  // four independent 16-byte loads in flight per thread
+            f32x4 v[4];
+            unsigned gm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(xs)[c + 256 * u];
+            if (copy_good) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gm[u] = gs[c + 256 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(c + 256 * u, v[u], gm[u]);
         }
+        for (; c < gv; c += 256) emit(c, reinterpret_cast<const f32x4*>(xs)[c], copy_good ? gs[c] : 0u);
     } else {
         for (int64_t c = threadIdx.x; c < G; c += 256) {
             const float v = xs[c];
@@ -802,6 +863,14 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
     dim3 g1((unsigned)((H + 127) / 128), nchunk);
 #define BCG_L(TI, CC, c0) \
     hipLaunchKernelGGL((bias_cond_stage1<TI, CC>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, ws)
+    const int W = dh_dtype == C2_F32 ? 4 : 8;
+    if (C == 0 && H % W == 0 && lddh % W == 0 && aligned16(dh) && H >= 1024) {
+        dim3 gv((unsigned)((H / W + 63) / 64), nchunk);
+        if (dh_dtype == C2_F32)
+            hipLaunchKernelGGL(bias_stage1_vec<float>, gv, dim3(256), 0, st, (const float*)dh, lddh, B, (int)H, ws);
+        else
+            hipLaunchKernelGGL(bias_stage1_vec<bf16_t>, gv, dim3(256), 0, st, (const bf16_t*)dh, lddh, B, (int)H, ws);
+    } else
     for (int c0 = 0; c0 == 0 || c0 < C; c0 += kBCG_MAXC) {
         const int left = C - c0;
         if (dh_dtype == C2_F32) {
