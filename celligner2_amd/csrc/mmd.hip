@@ -380,9 +380,255 @@ __global__ __launch_bounds__(64, FAST ? 3 : 1) void mmd_tile_kernel(const TF* __
     if (lane == 0 && dchunk == 0) loss_partials[(int64_t)js * gridDim.x + it] = beta * lacc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast instance for the latent features (fp32, D <= 64, 16-byte aligned rows): a block of four waves, each wave
+// owning one 32-row tile whose Gram operand stays in REGISTERS for the whole sweep; the four waves share every
+// 32-column tile, double-buffered in LDS and prefetched through registers (one block barrier per column tile).
+// Two waves per SIMD: one wave's fp32 MFMAs (Gram block, gradient contraction) run under the other's exponentials.
+// A kernel scale whose every term exp(-beta_k d) of the tile underflows to exactly 0 (beta_k * min d > 160 / log2 e:
+// at the reference's large 1/(2 alpha) scales that is every tile without near-duplicate rows) is skipped -- the
+// sums are bit-identical, only the work is not done.
+#ifndef C2_MMD_SKIP_T
+#define C2_MMD_SKIP_T 160.f  // 2^-160 is below the smallest fp32 denormal: the term is exactly 0
+#endif
+constexpr int FW = 4;  // waves (row tiles) per block
+#ifdef C2_MMD_DBG
+__device__ unsigned long long g_mmd_clk[8];
+#define MMD_T(i) { const unsigned long long t_ = clock64(); ph[i] += t_ - tprev; tprev = t_; }
+#else
+#define MMD_T(i)
+#endif
+__global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __restrict__ f, int64_t ldf,
+                                                              const int32_t* __restrict__ part_id,
+                                                              const float* __restrict__ wt,
+                                                              const float* __restrict__ norms, int64_t row0, int64_t Bl,
+                                                              int64_t Bg, int D, int nit, int jt_per, float beta,
+                                                              float* __restrict__ loss_partials,
+                                                              float* __restrict__ gslabs /*[jsplit][Bl][D]*/) {
+    __shared__ float ldsJ[2][TS * LDT];
+    __shared__ float ldsW[FW][TS * (TS + 1)];
+    __shared__ float ldsNi[FW][TS];
+    __shared__ int ldsPi[FW][TS];
+    __shared__ float ldsNj[2][TS];   // norms / partitions of the column tile, staged with it
+    __shared__ int ldsPj[2][TS];
+    __shared__ float ldsWt[MAXP * MAXP];  // the pair-weight table (16 KB): no global load inside the sweep
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < MAXP * MAXP; i += 64 * FW) ldsWt[i] = wt[i];
+    const int hi = lane >> 5, lo = lane & 31;
+    const int it = blockIdx.x * FW + wave, js = blockIdx.y;
+    const int64_t i0 = (int64_t)it * TS;
+    const bool active = it < nit;  // wave-uniform; an inactive wave still stages tiles and joins the barriers
+
+    // Gram A operand of this wave's rows: step s, lane (lo, hi) holds f[i0 + lo][2 s + hi]
+    float afr[DC / 2];
+    {
+        const bool ok = active && i0 + lo < Bl;
+        const float* fr = f + (row0 + i0 + lo) * ldf;
+#pragma unroll
+        for (int s2 = 0; s2 < DC / 2; ++s2) {
+            const int d = 2 * s2 + hi;
+            afr[s2] = (ok && d < D) ? fr[d] : 0.f;
+        }
+    }
+    // row norms / partitions of the wave's 32 rows live in LDS (read back per pair: registers are the scarce resource)
+    const int64_t gi0 = row0 + i0 + 4 * hi;
+    if (lane < TS) {
+        const bool ok = active && i0 + lane < Bl;
+        ldsNi[wave][lane] = ok ? norms[row0 + i0 + lane] : 0.f;
+        ldsPi[wave][lane] = ok ? part_id[row0 + i0 + lane] : -1;
+    }
+    const float* myNi = ldsNi[wave];
+    const int* myPi = ldsPi[wave];
+    f32x16 gacc[2];
+    float racc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { gacc[0][e] = 0.f; gacc[1][e] = 0.f; racc[e] = 0.f; }
+    float lacc = 0.f;
+
+    // column tile staging: 32 rows x 16 chunks of 4 features, two chunks per thread
+    f32x4 vn[2];
+    float vnj = 0.f;
+    int vpj = -1;
+    auto tile_load = [&](int64_t j0) {
+        if (tid < TS) {
+            const bool ok = j0 + tid < Bg;
+            vnj = ok ? norms[j0 + tid] : 0.f;
+            vpj = ok ? part_id[j0 + tid] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            vn[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < Bg && c4 < D) vn[k] = *reinterpret_cast<const f32x4*>(f + (j0 + r) * ldf + c4);
+        }
+    };
+    auto tile_store = [&](float* dst, int buf) {
+        if (tid < TS) {
+            ldsNj[buf][tid] = vnj;
+            ldsPj[buf][tid] = vpj;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[r * LDT + c4 + q] = vn[k][q];
+        }
+    };
+    const int64_t njt = (Bg + TS - 1) / TS;
+    const int64_t jt_beg = (int64_t)js * jt_per, jt_end = min(njt, jt_beg + jt_per);
+    if (jt_beg < jt_end) tile_load(jt_beg * TS);
+    float* myW = ldsW[wave];
+#ifdef C2_MMD_DBG
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = clock64();
+    const unsigned long long tstart = tprev;
+#endif
+    for (int64_t jt = jt_beg; jt < jt_end; ++jt) {
+        const int64_t j0 = jt * TS;
+        const int buf = (int)((jt - jt_beg) & 1);
+        float* tJ = ldsJ[buf];
+        tile_store(tJ, buf);
+        __syncthreads();  // tile jt visible; every wave is past its reads of the other buffer's previous tile
+        MMD_T(0)
+        if (jt + 1 < jt_end) tile_load((jt + 1) * TS);
+        if (!active) continue;
+        // ---- Gram block (fp32 MFMA: the distance is a cancellation)
+        // two independent accumulation chains: a dependent MFMA waits out the previous one's 16 passes (and whatever
+        // the SIMD's other wave slipped in between), two chains issue back to back
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < DC / 2; s2 += 2) {
+            if (2 * s2 < D) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s2], tJ[lo * LDT + 2 * s2 + hi], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s2 + 1], tJ[lo * LDT + 2 * s2 + 2 + hi], acc1, 0, 0, 0);
+            }
+            if ((s2 & 7) == 6) __builtin_amdgcn_sched_barrier(0);  // keep at most 8 operand reads in flight
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
+        const int64_t gj = j0 + lo;
+        const bool jok = gj < Bg;
+        const float nj = ldsNj[buf][lo];
+        const int pj = ldsPj[buf][lo];
+#ifdef C2_MMD_DBG
+        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(nj), "v"(pj));
+        MMD_T(1)
+#endif
+        // ---- squared distances of this lane's 16 pairs, and the tile's smallest one
+        // (pairs are kept two to a register pair so that the per-term multiply, add and fma are packed fp32 ops)
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 dd[8], S[8], Wp[8];
+        float dmin = INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            float d = fmaxf(myNi[r] + nj - 2.f * acc[e], 0.f);
+            if ((gi0 + ((e & 3) + 8 * (e >> 2))) == gj) d = 0.f;  // exact self distance
+            dd[e >> 1][e & 1] = d;
+            S[e >> 1][e & 1] = 0.f;
+            Wp[e >> 1][e & 1] = 0.f;
+            if (jok && myPi[r] >= 0) dmin = fminf(dmin, d);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+        const float dmin_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dmin)));
+        MMD_T(2)
+        // beta_k = 1/(2 alpha_k) folded at compile time in fp32, as the reference forms it (losses.py:156);
+        // exp(-beta d) = exp2(-beta log2(e) d) on v_exp_f32; terms in the reference's order
+#define C2_MMD_TERM(ALPHA)                                                  \
+    {                                                                       \
+        constexpr float bk = 1.0f / (2.0f * (ALPHA));                       \
+        constexpr float ck = -bk * 1.4426950408889634f;                     \
+        if (-ck * dmin_u < C2_MMD_SKIP_T) {                                 \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                 \
+                const f32x2 arg = ck * dd[e];                               \
+                f32x2 ex;                                                   \
+                ex[0] = __builtin_amdgcn_exp2f(arg[0]);                     \
+                ex[1] = __builtin_amdgcn_exp2f(arg[1]);                     \
+                S[e] += ex;                                                 \
+                Wp[e] = (2.f * bk) * ex + Wp[e];                            \
+            }                                                               \
+        }                                                                   \
+    }
+        C2_MMD_TERM(1e-6f) C2_MMD_TERM(1e-5f) C2_MMD_TERM(1e-4f) C2_MMD_TERM(1e-3f) C2_MMD_TERM(1e-2f)
+        C2_MMD_TERM(1e-1f) C2_MMD_TERM(1.f) C2_MMD_TERM(5.f) C2_MMD_TERM(10.f) C2_MMD_TERM(15.f)
+        C2_MMD_TERM(20.f) C2_MMD_TERM(25.f) C2_MMD_TERM(30.f) C2_MMD_TERM(35.f) C2_MMD_TERM(100.f)
+        C2_MMD_TERM(1e3f) C2_MMD_TERM(1e4f) C2_MMD_TERM(1e5f) C2_MMD_TERM(1e6f)
+#undef C2_MMD_TERM
+#ifdef C2_MMD_DBG
+        asm volatile("s_nop 0" :: "v"(S[0][0]), "v"(Wp[7][1]));
+        MMD_T(3)
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's contraction reads of myW (previous tile) are done
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2);
+            float w = 0.f;
+            const int pie = myPi[r + 4 * hi];
+            if (jok && pie >= 0) w = ldsWt[(unsigned)(pie * MAXP + pj)];
+            lacc += w * S[e >> 1][e & 1];
+            // a self pair adds K = 19 to the loss but no gradient (f_i - f_i = 0): drop its 1e6-scale weight,
+            // which would otherwise only cancel to fp32 rounding in G_i - r_i f_i
+            const float gw = ((gi0 + r) == gj) ? 0.f : w * Wp[e >> 1][e & 1];
+            racc[e] += gw;
+            myW[(r + 4 * hi) * (TS + 1) + lo] = gw;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: LDS is in order within a wave
+        MMD_T(4)
+        // ---- gradient contraction  G_i += sum_j gw_ij f_j
+#pragma unroll 4
+        for (int s2 = 0; s2 < TS / 2; ++s2) {
+            const float a = myW[lo * (TS + 1) + 2 * s2 + hi];
+            const float b0 = tJ[(2 * s2 + hi) * LDT + lo];
+            const float b1 = tJ[(2 * s2 + hi) * LDT + 32 + lo];
+            gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, gacc[0], 0, 0, 0);
+            gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, gacc[1], 0, 0, 0);
+        }
+#ifdef C2_MMD_DBG
+        asm volatile("s_nop 0" :: "v"(gacc[0][0]), "v"(gacc[1][15]));
+        MMD_T(5)
+#endif
+    }
+#ifdef C2_MMD_DBG
+    if (blockIdx.x == 3 && blockIdx.y == 5 && tid == 0) {
+        for (int i = 0; i < 6; ++i) g_mmd_clk[i] = ph[i];
+        g_mmd_clk[6] = clock64() - tstart;
+    }
+#endif
+    if (!active) return;
+    // ---- finish: r_i over the 32 column lanes, dfeat = 2*beta*(G_i - r_i f_i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) racc[e] += __shfl_xor(racc[e], o, 64);
+    }
+    float* slab = gslabs + (int64_t)js * Bl * D;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t li = i0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            const int dcol = h * 32 + lo;
+            if (li < Bl && dcol < D) {
+                const float fi = f[(row0 + li) * ldf + dcol];
+                slab[li * D + dcol] = 2.f * beta * (gacc[h][e] - racc[e] * fi);
+            }
+        }
+    lacc = wave_sum(lacc);
+    if (lane == 0) loss_partials[(int64_t)js * nit + it] = beta * lacc;
+}
+
 }  // namespace c2
 
 using namespace c2;
+
+#ifdef C2_MMD_DBG
+extern "C" int c2_dbg_mmd_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mmd_clk), 64); }
+#endif
 
 extern "C" size_t c2_partition_ws(int64_t B) { return (size_t)(B * 8 + 64); }
 
@@ -403,6 +649,16 @@ static void mmd_split(int64_t Bl, int64_t Bg, int& nit, int& jsplit, int& jt_per
     const int64_t njt = (Bg + TS - 1) / TS;
     int64_t js = std::max<int64_t>(1, std::min<int64_t>(njt, (4096 + nit - 1) / nit));
     while ((int64_t)nit * js > kReduceWsFloats && js > 1) --js;
+    jt_per = (int)((njt + js - 1) / js);
+    jsplit = (int)((njt + jt_per - 1) / jt_per);
+}
+
+// the four-wave fast kernel: at most 512 blocks = one round at 2 blocks per CU (a second, partial round would cost a
+// full sweep), never more slabs than the workspace holds
+static void mmd_split_fast(int64_t Bl, int64_t Bg, int nit, int jsplit_max, int& jsplit, int& jt_per) {
+    const int nitb = (nit + FW - 1) / FW;
+    const int64_t njt = (Bg + TS - 1) / TS;
+    int64_t js = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(njt, jsplit_max), std::max(1, 512 / nitb)));
     jt_per = (int)((njt + js - 1) / js);
     jsplit = (int)((njt + jt_per - 1) / jt_per);
 }
@@ -439,10 +695,11 @@ extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const 
         hipLaunchKernelGGL((row_norms_kernel<float>), dim3((unsigned)((Bg + 3) / 4)), dim3(256), 0, st, (const float*)feat,
                            ldf, Bg, (int)D, norms);
         const bool fast = D <= DC && (D & 3) == 0 && (ldf & 3) == 0 && aligned16(feat);
-        if (fast)
-            hipLaunchKernelGGL((mmd_tile_kernel<float, true>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt,
-                               norms, row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
-        else
+        if (fast) {
+            mmd_split_fast(Bl, Bg, nit, jsplit, jsplit, jt_per);
+            hipLaunchKernelGGL(mmd_fast_kernel, dim3((nit + FW - 1) / FW, jsplit), dim3(64 * FW), 0, st, (const float*)feat,
+                               ldf, part_id, wt, norms, row0, Bl, Bg, (int)D, nit, jt_per, beta, partials, slabs);
+        } else
             hipLaunchKernelGGL((mmd_tile_kernel<float, false>), grid, dim3(64), 0, st, (const float*)feat, ldf, part_id, wt,
                                norms, row0, Bl, Bg, (int)D, jt_per, beta, partials, slabs);
     }
