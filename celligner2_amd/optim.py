@@ -13,10 +13,29 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0,
-                 shadow_lookup=None):
+                 shadow_lookup=None, grad_sync=None):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
         super().__init__(params, defaults)
         self._shadow_lookup = shadow_lookup  # callable(param) -> bf16 shadow tensor or None
+        # data-parallel runs: object with deferred_range() / wait_deferred() (parallel.DataParallelStep).  Tensors whose
+        # gradient lies in the bucket that is still being all-reduced are updated by a second launch, after the wait.
+        self._grad_sync = grad_sync
+        if grad_sync is not None:
+            grad_sync.defer_last = True
+
+    def _launch(self, group, entries, step_t):
+        rng = self._grad_sync.deferred_range() if self._grad_sync is not None else None
+        hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
+                 group.get("clip_value", 0.0), step_t)
+        if rng is not None:
+            late = [e for e in entries if rng[0] <= e[1].data_ptr() < rng[1]]
+            early = [e for e in entries if not (rng[0] <= e[1].data_ptr() < rng[1])]
+            if early:
+                ops.adam_step(early, *hyper)
+            self._grad_sync.wait_deferred()
+            entries = late
+        if entries:
+            ops.adam_step(entries, *hyper)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -40,13 +59,13 @@ class FusedAdam(torch.optim.Optimizer):
                     step_t = st["step"]
                 elif step_t != st["step"]:
                     # tensors that joined later: flush what we have and start a new launch
-                    ops.adam_step(entries, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                                  group["weight_decay"], group.get("clip_value", 0.0), step_t)
+                    self._launch(group, entries, step_t)
                     entries, step_t = [], st["step"]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 sh = self._shadow_lookup(p) if self._shadow_lookup is not None else None
                 entries.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], sh))
             if entries:
-                ops.adam_step(entries, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                              group["weight_decay"], group.get("clip_value", 0.0), step_t)
+                self._launch(group, entries, step_t)
+        if self._grad_sync is not None:
+            self._grad_sync.wait_deferred()  # nothing of the step may outlive it un-synchronised
         return loss

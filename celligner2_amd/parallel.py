@@ -30,6 +30,8 @@ class DataParallelStep:
         self.rank = dist.get_rank(group)
         self._side = None
         self._pending = []
+        self.defer_last = False  # set by the optimizer wiring: the last bucket's wait moves into FusedAdam.step
+        self._deferred = None    # (event, first byte, one-past-last byte) of the bucket still being reduced
 
     # -- wiring
     def attach_model(self, model):
@@ -82,11 +84,25 @@ class DataParallelStep:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 done = torch.cuda.Event()
                 done.record(self._side)
-            self._pending.append(done)
+            self._pending.append((done, flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def wait_all(self):
-        for ev in self._pending:
-            torch.cuda.current_stream().wait_event(ev)
+        """Order the compute stream after the bucket all-reduces.  With `defer_last`, the newest bucket (the encoder's
+        gene-width layer, reduced last) is left in flight: FusedAdam updates every other tensor first and calls
+        wait_deferred() before it touches that bucket -- the optimizer overlaps the exposed tail of the exchange."""
+        pend = self._pending
         self._pending = []
+        if self.defer_last and len(pend) > 1:
+            self._deferred = pend.pop()
+        for ev, _, _ in pend:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def deferred_range(self):
+        return None if self._deferred is None else self._deferred[1:]
+
+    def wait_deferred(self):
+        if self._deferred is not None:
+            torch.cuda.current_stream().wait_event(self._deferred[0])
+            self._deferred = None

@@ -42,10 +42,17 @@ def main():
         m.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=False)  # BN buffers: defaults
         return m.cuda().train()
 
-    def run(m, sl):
+    from celligner2_amd.optim import FusedAdam
+
+    def run(m, sl, sync=None):
+        """One full step (forward, backward, fused Adam).  sync: the communicator -- the optimizer then updates the
+        tensors of the bucket that is still being all-reduced in a second launch, after the wait."""
+        opt = FusedAdam(list(m.parameters()), lr=1e-3, eps=0.01, weight_decay=0.04, grad_sync=sync)
         m._forced_noise = dict(eps=torch.tensor(eps[sl]).cuda(), masks={})
         r, k, mm, ce = m(**{k_: torch.tensor(v[sl]).cuda() for k_, v in full.items()})
         (r + 1e-3 * k + mm + ce).backward()
+        opt.step()
+        torch.cuda.synchronize()
         return np.array([r.item(), k.item(), mm.item(), ce.item()]), {n: p.grad.clone() for n, p in m.named_parameters()}
 
     ref_l = ref_g = ref_m = None
@@ -56,7 +63,8 @@ def main():
     comm = DataParallelStep()
     comm.attach_model(m)
     per = B // world
-    losses, grads = run(m, slice(rank * per, (rank + 1) * per))
+    losses, grads = run(m, slice(rank * per, (rank + 1) * per), sync=comm)
+    assert comm.defer_last and comm.deferred_range() is None
     m._engine().check_status()
     ok = True
     if rank == 0:
@@ -74,6 +82,11 @@ def main():
             if err > 1e-4:
                 ok = False
                 print("MISMATCH", n, err)
+        for n, p in ref_m.named_parameters():  # parameters after the optimizer step
+            err = (dict(m.named_parameters())[n].detach() - p.detach()).abs().max().item() / max(p.abs().max().item(), 1e-30)
+            if err > 1e-5:
+                ok = False
+                print("MISMATCH param after Adam", n, err)
         print("losses ddp", losses, "single", ref_l)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
