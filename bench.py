@@ -137,8 +137,9 @@ def main():
     model.train()
     names = {id(p): n for n, p in model.named_parameters()}
     from celligner2_amd.optim import FusedAdam
+    lookup, updated = model._adam_hooks()
     trainer.optimizer = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=0.01,
-                                  weight_decay=0.04, shadow_lookup=lambda p: model._engine().shadow_for_adam(names[id(p)]),
+                                  weight_decay=0.04, shadow_lookup=lookup, on_updated=updated,
                                   grad_sync=getattr(trainer, "world", None))
     trainer.epoch, trainer.iter = 0, 0
     from collections import defaultdict

@@ -25,7 +25,7 @@ i64, i32, f32, f64, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64)]
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp)]
 
 
 _SIGS = {

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
     const int64_t base = (int64_t)(blockIdx.x - tab.first_block[ti]) * kElemsPerBlock;
     const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
                        reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0 &&
-                     (!t.shadow_bf16 || (reinterpret_cast<uintptr_t>(t.shadow_bf16) & 7) == 0);
+                     (!t.shadow_bf16 || (reinterpret_cast<uintptr_t>(t.shadow_bf16) & 7) == 0) &&
+                     (!t.shadow_lo || (reinterpret_cast<uintptr_t>(t.shadow_lo) & 7) == 0);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
@@ -60,13 +61,26 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
                 pk[0] = (unsigned)f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
                 pk[1] = (unsigned)f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
+                if (t.shadow_lo) {
+                    bf16_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = f2bf(p[e] - bf2f(f2bf(p[e])));
+                    u32x2 pl;
+                    pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+                    pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_lo) + i) = pl;
+                }
             }
         } else {
             for (int e = 0; e < 4 && i + e < t.n; ++e) {
                 float pe = t.p[i + e], me = t.m[i + e], ve = t.v[i + e];
                 adam_one(pe, t.g[i + e], me, ve, h);
                 t.p[i + e] = pe; t.m[i + e] = me; t.v[i + e] = ve;
-                if (t.shadow_bf16) reinterpret_cast<bf16_t*>(t.shadow_bf16)[i + e] = f2bf(pe);
+                if (t.shadow_bf16) {
+                    const bf16_t hb = f2bf(pe);
+                    reinterpret_cast<bf16_t*>(t.shadow_bf16)[i + e] = hb;
+                    if (t.shadow_lo) reinterpret_cast<bf16_t*>(t.shadow_lo)[i + e] = f2bf(pe - bf2f(hb));
+                }
             }
         }
     }
@@ -96,6 +110,7 @@ extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, doub
             const c2_adam_tensor& d = desc_host[i];
             if (d.n == 0) continue;
             C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");
+            C2_CHECK(!d.shadow_lo || d.shadow_bf16, "shadow_lo without the high plane");
             tab.t[tab.n] = d;
             tab.first_block[tab.n] = blocks;
             blocks += (int)((d.n + kElemsPerBlock - 1) / kElemsPerBlock);

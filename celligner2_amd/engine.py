@@ -188,7 +188,26 @@ class StepEngine:
         return sh
 
     def shadow_for_adam(self, name):
-        return self._shadow.get(name) if self.T != F32 else None
+        """What the fused Adam kernel refreshes together with the fp32 master weight: the bf16 shadow of a gene-width
+        layer, or the (hi, lo) bf16 planes of a narrow layer's weight (the kernel writes through raw pointers, so
+        torch's version counter does not move: without this the operand copies would go stale after a step)."""
+        if self.T == F32:
+            return None
+        sh = self._shadow.get(name)
+        if sh is not None:
+            return sh
+        c = self._wplanes.get(name)
+        return c[1] if c is not None else None
+
+    def copies_current(self, name):
+        """The optimizer has just refreshed this parameter's operand copy in its own kernel and advanced the
+        parameter's version counter: record that version, so that the next forward does not convert again."""
+        p = self.p[name]
+        if name in self._shadow:
+            self._shadow_ver[name] = p._version
+        c = self._wplanes.get(name)
+        if c is not None:
+            self._wplanes[name] = (p._version, c[1])
 
     def as_dtype(self, key, t, dtype):
         """Operand view of an fp32 activation in `dtype` (a bf16 copy when the consumer GEMM is gene-width)."""

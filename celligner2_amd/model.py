@@ -127,7 +127,7 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, eps, masks, *params):
-        eng = model._engine()
+        eng = model.__dict__["_eng"]  # validated by Celligner2.forward just before
         losses = eng.forward(batch, eps, masks, train=model.training, save=True)
         ctx.model = model
         out = losses.clone()
@@ -136,7 +136,7 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1, g2, g3):
         model = ctx.model
-        eng = model._engine()
+        eng = model.__dict__["_eng"]
         g = torch.stack([gi if gi is not None else torch.zeros((), device=eng.dev) for gi in (g0, g1, g2, g3)]).float()
         grads = eng.backward(g)
         names = model._param_names
@@ -158,7 +158,7 @@ class _StepTotalFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, eps, masks, weights, *params):
-        eng = model._engine()
+        eng = model.__dict__["_eng"]  # validated by Celligner2.forward just before
         losses = eng.forward(batch, eps, masks, train=model.training, save=True)
         out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
         ops.combine_losses(losses, weights, out6)
@@ -171,7 +171,7 @@ class _StepTotalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _g6):
         model = ctx.model
-        eng = model._engine()
+        eng = model.__dict__["_eng"]
         g = ops.scale4(gtotal.float().contiguous() if gtotal is not None else None, ctx.weights, eng.buf("gseed", (4,)))
         grads = eng.backward(g)
         names, params = model._param_names, model._param_list
@@ -314,7 +314,7 @@ class Celligner2(nn.Module):
                                 "(model.cuda()); there is no CPU path")
         eng = self.__dict__["_eng"]
         cfg = self._cfg()
-        bns = {n: m for n, m in self.named_modules() if isinstance(m, _BatchNorm)}
+        bns = {n: m for n, m in self.named_modules() if isinstance(m, _BatchNorm)} if self.use_bn else {}
         stale = (eng is None or eng.dev != dev or eng.cfg != cfg or eng.precision != self.precision
                  or any(eng.p.get(n) is not p for n, p in params.items()) or len(eng.p) != len(params)
                  or any(eng.bn.get(n) is not m or m.running_mean.device != dev for n, m in bns.items()))
@@ -326,6 +326,22 @@ class Celligner2(nn.Module):
         self.__dict__["_param_names"] = list(params.keys())
         self.__dict__["_param_list"] = list(params.values())
         return eng
+
+    def _adam_hooks(self):
+        """(shadow_lookup, on_updated) for optim.FusedAdam: the operand copies of the CURRENT engine (no staleness
+        scan: these run once per parameter and step on the host's critical path)."""
+        names = {id(p): n for n, p in self.named_parameters()}
+
+        def lookup(p):
+            eng = self.__dict__["_eng"]
+            return eng.shadow_for_adam(names[id(p)]) if eng is not None else None
+
+        def updated(p):
+            eng = self.__dict__["_eng"]
+            if eng is not None:
+                eng.copies_current(names[id(p)])
+
+        return lookup, updated
 
     def _dropout_shapes(self, B):
         out = []

@@ -426,16 +426,21 @@ def mmd(feat, part_id, wt, row0, Bl, beta, loss_out, dfeat, ws):
 
 
 def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
-    """entries: list of (p, g, m, v, shadow_or_None) contiguous fp32 tensors."""
+    """entries: list of (p, g, m, v, shadow_or_None) contiguous fp32 tensors; shadow: a bf16 copy of p's shape, or the
+    [2, *p.shape] bf16 planes (hi, lo) of a C2_BF16X3P operand."""
     n = len(entries)
     arr = (L.AdamTensor * max(n, 1))()
     for i, (p, g, m, v, sh) in enumerate(entries):
         L.require_gpu(p, g, m, v)
         assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
         assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and g.numel() == p.numel()
+        lo = None
         if sh is not None:
-            assert sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == p.numel()
-        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel())
+            assert sh.dtype == torch.bfloat16 and sh.is_contiguous()
+            if sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
+                sh, lo = sh[0], sh[1]
+            assert sh.numel() == p.numel()
+        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo))
     check(lib.c2_adam_step(arr, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                            float(clip_value), int(step_t), stream()))
 

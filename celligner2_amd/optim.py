@@ -13,10 +13,14 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0,
-                 shadow_lookup=None, grad_sync=None):
+                 shadow_lookup=None, grad_sync=None, on_updated=None):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
         super().__init__(params, defaults)
-        self._shadow_lookup = shadow_lookup  # callable(param) -> bf16 shadow tensor or None
+        self._shadow_lookup = shadow_lookup  # callable(param) -> bf16 shadow / planes tensor or None
+        # The kernel writes the parameters through raw pointers; step() then advances each parameter's autograd version
+        # counter (as an in-place torch op would), so that anything caching a function of the weights sees the change.
+        # on_updated(param) is called right after that for parameters whose operand copy the kernel refreshed itself.
+        self._on_updated = on_updated
         # data-parallel runs: object with deferred_range() / wait_deferred() (parallel.DataParallelStep).  Tensors whose
         # gradient lies in the bucket that is still being all-reduced are updated by a second launch, after the wait.
         self._grad_sync = grad_sync
@@ -43,6 +47,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        touched, refreshed = [], []
         for group in self.param_groups:
             entries = []
             step_t = None
@@ -64,8 +69,16 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 sh = self._shadow_lookup(p) if self._shadow_lookup is not None else None
                 entries.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], sh))
+                touched.append(p)
+                if sh is not None:
+                    refreshed.append(p)
             if entries:
                 self._launch(group, entries, step_t)
         if self._grad_sync is not None:
             self._grad_sync.wait_deferred()  # nothing of the step may outlive it un-synchronised
+        if touched:
+            torch._C._autograd._unsafe_set_version_counter(tuple(touched), tuple(p._version + 1 for p in touched))
+            if self._on_updated is not None:
+                for p in refreshed:
+                    self._on_updated(p)
         return loss

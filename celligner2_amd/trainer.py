@@ -267,10 +267,10 @@ class Trainer:
         eng = self.model._engine()
         names = {id(p): n for n, p in self.model.named_parameters()}
         params = [p for p in self.model.parameters() if p.requires_grad]
+        lookup, updated = self.model._adam_hooks()
         self.optimizer = FusedAdam(params, lr=lr, eps=eps, weight_decay=self.weight_decay,
                                    clip_value=self.clip_value,
-                                   shadow_lookup=lambda p: self.model._engine().shadow_for_adam(names[id(p)]),
-                                   grad_sync=getattr(self, "world", None))
+                                   shadow_lookup=lookup, on_updated=updated, grad_sync=getattr(self, "world", None))
         self.before_loop()
         for self.epoch in range(n_epochs):
             self.on_epoch_begin(lr, eps)

@@ -194,8 +194,8 @@ int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* pa
 
 /* torch.optim.Adam step as trainer.py:262-266,316-323 configures it (L2 weight decay added to the gradient,
  * optional clip_grad_value_), over a table of tensors.  desc_host: array of n c2_adam_tensor (HOST memory,
- * copied by value into the launch).  step_t >= 1.  shadow (bf16 copy of the updated weights, may be NULL)
- * is refreshed in the same pass for bf16-operand GEMMs.  Hyper-parameters are doubles so that 1-beta and the bias
+ * copied by value into the launch).  step_t >= 1.  shadow (bf16 copy of the updated weights, may be NULL; with
+ * shadow_lo the two bf16 planes) is refreshed in the same pass for the bf16-operand GEMMs.  Hyper-parameters are doubles so that 1-beta and the bias
  * corrections are formed exactly as torch forms them (in double, then rounded to fp32). */
 typedef struct {
     float* p;
@@ -204,6 +204,8 @@ typedef struct {
     float* v;
     void* shadow_bf16; /* NULL or [n] bf16 */
     int64_t n;
+    void* shadow_lo;   /* NULL, or [n] bf16: the low plane lo = bf16(p - hi) next to shadow_bf16 = hi = bf16(p), the
+                          C2_BF16X3P operand form of the fp32 weights of the narrow layers */
 } c2_adam_tensor;
 int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
                  double weight_decay, double clip_value, int64_t step_t, void* stream);

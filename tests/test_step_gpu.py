@@ -281,3 +281,55 @@ def test_surgery_query_model_step_vs_oracle():
     opt.step()
     for n, v in q.state_dict().items():
         assert torch.equal(v, before[n]) == (n not in trainable), n
+
+
+def test_bf16_operand_copies_follow_the_optimizer():
+    """bf16 mode keeps operand copies of the fp32 master weights (bf16 shadows of the gene-width layers, (hi, lo)
+    planes of the narrow ones).  The fused Adam kernel updates the masters through raw pointers, so it must refresh
+    the copies itself: after every step they equal a fresh conversion bit for bit, and the next forward equals
+    that of an engine built from scratch on the same parameters."""
+    from celligner2_amd import ops
+    from celligner2_amd.model import Celligner2
+    from celligner2_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    G, hidden, L, C, B = 4096, [512, 256], 64, 3, 256
+    m = Celligner2(G, hidden, L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=10.0,
+                   precision="bf16").to(DEV).train()
+    names = {id(p): n for n, p in m.named_parameters()}
+    opt = FusedAdam(list(m.parameters()), lr=1e-2, eps=0.01, weight_decay=0.04,
+                    shadow_lookup=lambda p: m._engine().shadow_for_adam(names[id(p)]),
+                    on_updated=lambda p: m._engine().copies_current(names[id(p)]))
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.poisson(3.0, (B, G)).astype(np.float32)).to(DEV)
+    cond = torch.zeros(B, C, dtype=torch.int64, device=DEV)
+    cond[torch.arange(B), torch.randint(0, C, (B,))] = 1
+    eps = torch.randn(B, L, device=DEV)
+    m._forced_noise = dict(eps=eps, masks={})
+    for step in range(3):
+        r, k, mm, ce = m(x=x, batch=cond, sizefactor=x.sum(1))
+        (r + 1e-3 * k + mm + ce).backward()
+        opt.step()
+        opt.zero_grad()
+        eng = m._engine()
+        params = dict(m.named_parameters())
+        assert len(eng._wplanes) >= 4 and len(eng._shadow) == 2
+        for n, sh in eng._shadow.items():
+            assert torch.equal(sh, params[n].detach().to(torch.bfloat16)), (n, step)
+        for n, (_, pl) in eng._wplanes.items():
+            assert torch.equal(pl, ops.split_bf16(params[n].detach())), (n, step)
+    with torch.no_grad():
+        kept = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
+        m.__dict__["_eng"] = None  # fresh engine: every operand copy rebuilt from the masters
+        fresh = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
+    assert kept == fresh
+    # an optimizer that knows nothing of the copies (no shadow_lookup): the version counters it advances make the
+    # engine convert again
+    opt2 = FusedAdam(list(m.parameters()), lr=1e-2, eps=0.01, weight_decay=0.04)
+    r, k, mm, ce = m(x=x, batch=cond, sizefactor=x.sum(1))
+    (r + 1e-3 * k + mm + ce).backward()
+    opt2.step()
+    with torch.no_grad():
+        kept = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
+        m.__dict__["_eng"] = None
+        fresh = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
+    assert kept == fresh
