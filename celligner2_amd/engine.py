@@ -125,8 +125,8 @@ class StepEngine:
         order += ["classifier.classifier.0.weight", "classifier.classifier.0.bias"]
         for blk in reversed(self.cls):
             order += gb(blk) + [blk.w]
-        order += ["encoder.mean_encoder.weight", "encoder.mean_encoder.bias", "encoder.log_var_encoder.weight",
-                  "encoder.log_var_encoder.bias"]
+        order += ["encoder.mean_encoder.weight", "encoder.log_var_encoder.weight", "encoder.mean_encoder.bias",
+                  "encoder.log_var_encoder.bias"]  # (pairs adjacent: _build_arena glues them)
         for blk in reversed(self.enc):
             order += gb(blk) + [blk.w, blk.b, blk.wc]
         seen, out = set(), []
@@ -145,10 +145,15 @@ class StepEngine:
             return
         self._arena_key = key
         names = [n for n in self._readiness_order() if self.p[n].requires_grad]
-        offs, total = {}, 0
+        # the two latent heads' weights (and biases) lie back to back, so that one [2L, H] ([2L]) view spans both
+        glued = {self.HEADS[1] + ".weight": self.HEADS[0] + ".weight", self.HEADS[1] + ".bias": self.HEADS[0] + ".bias"}
+        offs, total, prev = {}, 0, None
         for n in names:
+            if prev is not None and glued.get(n) == prev and self.p[prev].numel() % 4 == 0:  # (16-byte alignment)
+                total = offs[prev] + self.p[prev].numel()
             offs[n] = total
             total += (self.p[n].numel() + 63) // 64 * 64
+            prev = n
         self.grad_flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
         self.grad = {n: self.grad_flat[offs[n]:offs[n] + self.p[n].numel()].view(self.p[n].shape) for n in names}
         first = {self.head + ".weight", self.head + ".bias", "theta"}
@@ -157,9 +162,10 @@ class StepEngine:
         last = {self.enc[0].w, self.enc[0].b, self.enc[0].wc}
         if self.enc[0].norm:
             last |= {self.enc[0].norm + ".weight", self.enc[0].norm + ".bias"}
-        b0 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in first)
-        b2 = sum((self.p[n].numel() + 63) // 64 * 64 for n in names if n in last)
-        self.buckets = [(0, b0), (b0, total - b2), (total - b2, total)]
+        ends = {n: offs[n] + (self.p[n].numel() + 63) // 64 * 64 for n in names}
+        b0 = max([ends[n] for n in names if n in first], default=0)            # readiness order: `first` leads,
+        lo2 = min([offs[n] for n in names if n in last], default=total)        # `last` closes the arena
+        self.buckets = [(0, b0), (b0, lo2), (lo2, total)]
 
     def gbuf(self, name):
         self._build_arena()
@@ -174,6 +180,8 @@ class StepEngine:
 
     def weight(self, name):
         """GEMM operand view of a weight: the fp32 parameter itself, or its bf16 shadow."""
+        if name == self.HEADW:
+            return self._ws["heads.W"]
         p = self.p[name]
         if self.gemm_dtype(name) == F32:
             return p.detach()
@@ -197,7 +205,15 @@ class StepEngine:
         if sh is not None:
             return sh
         c = self._wplanes.get(name)
-        return c[1] if c is not None else None
+        if c is not None:
+            return c[1]
+        if name in (self.HEADS[0] + ".weight", self.HEADS[1] + ".weight"):
+            c = self._wplanes.get(self.HEADW)  # rows [0,L) / [L,2L) of the stacked planes: (hi, lo) of this head
+            if c is not None:
+                L = self.p[name].shape[0]
+                k = 0 if name.startswith(self.HEADS[0]) else 1
+                return (c[1][0, k * L:(k + 1) * L], c[1][1, k * L:(k + 1) * L])
+        return None
 
     def copies_current(self, name):
         """The optimizer has just refreshed this parameter's operand copy in its own kernel and advanced the
@@ -208,6 +224,9 @@ class StepEngine:
         c = self._wplanes.get(name)
         if c is not None:
             self._wplanes[name] = (p._version, c[1])
+        c = self._wplanes.get(self.HEADW)
+        if c is not None and name in (self.HEADS[0] + ".weight", self.HEADS[1] + ".weight"):
+            self._wplanes[self.HEADW] = (self._heads_version(), c[1])
 
     def as_dtype(self, key, t, dtype):
         """Operand view of an fp32 activation in `dtype` (a bf16 copy when the consumer GEMM is gene-width)."""
@@ -216,6 +235,42 @@ class StepEngine:
         out = self.buf(key, t.shape, dtype)
         ops.prep_input(t, out, False)
         return out
+
+    # ------------------------------------------------------------------ fused latent heads
+    # mean_encoder and log_var_encoder read the same activation and have the same shape: they run as ONE GEMM
+    # [B, 2L] = henc @ [W_mean; W_logvar]^T (forward, dgrad, wgrad).  The two weight (bias) parameters are made
+    # views of one [2L, H] ([2L]) buffer -- state_dict, optimizer and checkpoints see two ordinary parameters.
+    HEADS = ("encoder.mean_encoder", "encoder.log_var_encoder")
+    HEADW = "@heads"  # virtual weight name of the stacked matrix
+
+    def _heads_fusable(self):
+        wm, wl = (self.p[h + ".weight"] for h in self.HEADS)
+        bm, bl = (self.p[h + ".bias"] for h in self.HEADS)
+        return (wm.shape == wl.shape and self.gemm_dtype(self.HEADS[0] + ".weight") == F32
+                and wm.requires_grad == wl.requires_grad and bm.requires_grad == bl.requires_grad
+                and wm.dtype == F32 and wl.dtype == F32 and wm.numel() % 4 == 0 and bm.numel() % 4 == 0)
+
+    def _fuse_heads(self):
+        """Make (or keep) the two heads' parameters views of the stacked buffers; returns (W [2L,H], b [2L])."""
+        wm, wl = (self.p[h + ".weight"] for h in self.HEADS)
+        bm, bl = (self.p[h + ".bias"] for h in self.HEADS)
+        L, H = wm.shape
+        W = self._ws.get("heads.W")
+        b = self._ws.get("heads.b")
+        ok = (W is not None and tuple(W.shape) == (2 * L, H) and wm.data_ptr() == W.data_ptr()
+              and wl.data_ptr() == W[L:].data_ptr() and bm.data_ptr() == b.data_ptr()
+              and bl.data_ptr() == b[L:].data_ptr())
+        if not ok:
+            W = torch.cat([wm.detach(), wl.detach()], 0).contiguous()
+            b = torch.cat([bm.detach(), bl.detach()], 0).contiguous()
+            wm.data, wl.data = W[:L], W[L:]
+            bm.data, bl.data = b[:L], b[L:]
+            self._ws["heads.W"], self._ws["heads.b"] = W, b
+            self._wplanes.pop(self.HEADW, None)
+        return W, b
+
+    def _heads_version(self):
+        return tuple(self.p[h + ".weight"]._version for h in self.HEADS)
 
     # ------------------------------------------------------------------ helpers
     # bf16 mode, narrow (fp32-operand) GEMMs: both operands are split ONCE into bf16 planes (hi, lo) and multiplied
@@ -239,6 +294,14 @@ class StepEngine:
         return pl
 
     def _wplanes_of(self, name):
+        if name == self.HEADW:
+            W, ver = self._ws["heads.W"], self._heads_version()
+            c = self._wplanes.get(name)
+            if c is None or c[0] != ver or c[1].shape[1:] != W.shape:
+                pl = c[1] if (c is not None and c[1].shape[1:] == W.shape) else None
+                c = (ver, ops.split_bf16(W, pl))
+                self._wplanes[name] = c
+            return c[1]
         p = self.p[name]
         c = self._wplanes.get(name)
         if c is None or c[0] != p._version or c[1].shape[1:] != p.shape:
@@ -283,10 +346,11 @@ class StepEngine:
         ops.linear_fwd(a2, w2, y, nslab=ns, x3=self.x3)
         return y
 
-    def _wgrad(self, dy, a, name, alpha=None):
+    def _wgrad(self, dy, a, name, alpha=None, g=None):
         """grad[name] = alpha * dy^T a; a short-and-wide weight gradient splits the batch reduction into slabs so
         that the launch fills the chip, then sums them (deterministic)."""
-        g = self.gbuf(name)
+        if g is None:
+            g = self.gbuf(name)
         N, K = g.shape
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
         if not pl and self._wgrad_two_part(dy, a, g, alpha):
@@ -348,6 +412,21 @@ class StepEngine:
         ops.epilogue_fwd(y, bias, cond if blk.use_cond else None, wc, mask, p if mask is not None else 0.0,
                          self.cfg["use_ln"], act, yhat, rstd, planes=planes)
         return act
+
+    def _heads_fwd(self, a, B, L):
+        """mu, logvar [B, L] (views): one stacked GEMM when the two heads can share it, else two."""
+        self._heads_fused = self._heads_fusable()
+        if self._heads_fused:
+            W, b = self._fuse_heads()
+            mulv = self.buf("mulv.cat", (B, 2 * L))
+            self._fwd(a, self.HEADW, mulv, bias=b)
+            self._mu, self._lv = mulv[:, :L], mulv[:, L:]
+        else:
+            mulv = self.buf("mulv", (2, B, L))
+            for k, h in enumerate(self.HEADS):
+                self._fwd(a, h + ".weight", mulv[k], bias=self.p[h + ".bias"].detach())
+            self._mu, self._lv = mulv[0], mulv[1]
+        return self._mu, self._lv
 
     def _bn_fwd(self, blk, y, bias, cond, wc, mask, p, act, planes, train):
         """BatchNorm1d tail (modules.py:298-302): statistics of the (global) batch in train mode, the running ones
@@ -460,14 +539,12 @@ class StepEngine:
             a = self._block_fwd(blk, a, cond, masks, train, save)
         self._henc = a
         L = cfg["latent"]
-        mulv = self.buf("mulv", (2, B, L))
-        self._fwd(a, "encoder.mean_encoder.weight", mulv[0], bias=self.p["encoder.mean_encoder.bias"].detach())
-        self._fwd(a, "encoder.log_var_encoder.weight", mulv[1], bias=self.p["encoder.log_var_encoder.bias"].detach())
+        mu, lv = self._heads_fwd(a, B, L)
         z32 = self.buf("z32", (B, L))
         red_ws = self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),))
         zdt = self.dec[0].gt
         zt = self.buf("zt", (B, L), zdt) if zdt != F32 else z32
-        ops.reparam_kl_fwd(mulv[0], mulv[1], eps, inv_B, cfg["use_own_kl"], z32, zt if zdt != F32 else None,
+        ops.reparam_kl_fwd(mu, lv, eps, inv_B, cfg["use_own_kl"], z32, zt if zdt != F32 else None,
                            losses[1:2], red_ws)
         # ---- decoder
         d = zt
@@ -614,20 +691,40 @@ class StepEngine:
             self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[nz:nz + 1])
         # ---- reparameterisation + KL
         on_z = cfg["use_mmd"] and cfg["mmd_on"] == "z"
-        mulv = self._ws["mulv"]
-        dml = self.buf("dmulv", (2, B, L), self.gemm_dtype("encoder.mean_encoder.weight"))
-        ops.reparam_kl_bwd(dz_all, mulv[0], mulv[1], self._eps, 1.0 / (B * self.world_size), cfg["use_own_kl"], gk,
-                           dml[0], dml[1], extra=self._dfeat if on_z else None, extra_scale=gm if on_z else None)
+        mu, lv = self._mu, self._lv
         henc = self._henc
         Hk = henc.shape[1]
-        da = self.buf("dheads.da", (2, B, Hk))
-        for k, nm in enumerate(("encoder.mean_encoder", "encoder.log_var_encoder")):
-            if rq(nm + ".weight"):
-                self._wgrad(dml[k], henc, nm + ".weight")
-            if rq(nm + ".bias"):
-                ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
-                ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
-            self._dgrad(dml[k], nm + ".weight", da[k:k + 1])
+        inv_Bg = 1.0 / (B * self.world_size)
+        xz, xs = (self._dfeat, gm) if on_z else (None, None)
+        if self._heads_fused:
+            dml = self.buf("dmulv.cat", (B, 2 * L))
+            ops.reparam_kl_bwd(dz_all, mu, lv, self._eps, inv_Bg, cfg["use_own_kl"], gk, dml[:, :L], dml[:, L:],
+                               extra=xz, extra_scale=xs)
+            wn, bn_ = [h + ".weight" for h in self.HEADS], [h + ".bias" for h in self.HEADS]
+            if rq(wn[0]):  # one [2L, H] view over the two (adjacent) gradient tensors
+                g0 = self.gbuf(wn[0])
+                self.gbuf(wn[1])
+                g = self.grad_flat[g0.storage_offset():g0.storage_offset() + 2 * L * Hk].view(2 * L, Hk)
+                self._wgrad(dml, henc, None, g=g)
+            if rq(bn_[0]):
+                b0 = self.gbuf(bn_[0])
+                self.gbuf(bn_[1])
+                ws = self.buf("bcg.ws.2L", (ops.bias_cond_grad_ws(B, 2 * L, 0),))
+                ops.bias_cond_grad(dml, None, self.grad_flat[b0.storage_offset():b0.storage_offset() + 2 * L], None, ws)
+            da = self.buf("dheads.da.cat", (self._dgrad_nslab(dml, self.HEADW), B, Hk))
+            self._dgrad(dml, self.HEADW, da)
+        else:
+            dml = self.buf("dmulv", (2, B, L), self.gemm_dtype("encoder.mean_encoder.weight"))
+            ops.reparam_kl_bwd(dz_all, mu, lv, self._eps, inv_Bg, cfg["use_own_kl"], gk, dml[0], dml[1], extra=xz,
+                               extra_scale=xs)
+            da = self.buf("dheads.da", (2, B, Hk))
+            for k, nm in enumerate(self.HEADS):
+                if rq(nm + ".weight"):
+                    self._wgrad(dml[k], henc, nm + ".weight")
+                if rq(nm + ".bias"):
+                    ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
+                    ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
+                self._dgrad(dml[k], nm + ".weight", da[k:k + 1])
         # ---- encoder blocks
         need = self._first_trainable_enc()
         for i in range(len(self.enc) - 1, -1, -1):
@@ -666,17 +763,15 @@ class StepEngine:
         for blk in self.enc:
             a = self._block_fwd(blk, a, cond, {}, False, False)
         L = cfg["latent"]
-        mulv = self.buf("mulv", (2, B, L))
-        self._fwd(a, "encoder.mean_encoder.weight", mulv[0], bias=self.p["encoder.mean_encoder.bias"].detach())
-        self._fwd(a, "encoder.log_var_encoder.weight", mulv[1], bias=self.p["encoder.log_var_encoder.bias"].detach())
+        mu, lv = self._heads_fwd(a, B, L)
         z = None
         if eps is not None:
             z = self.buf("z32", (B, L))
             scratch = self.buf("losses.scratch", (1,))
             scratch.zero_()
-            ops.reparam_kl_fwd(mulv[0], mulv[1], eps, 1.0 / B, cfg["use_own_kl"], z, None, scratch,
+            ops.reparam_kl_fwd(mu, lv, eps, 1.0 / B, cfg["use_own_kl"], z, None, scratch,
                                self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),)))
-        return mulv[0], mulv[1], z
+        return mu, lv, z
 
     def classify(self, z):
         self._aplanes = {}

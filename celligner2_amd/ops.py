@@ -435,9 +435,12 @@ def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
         assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
         assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and g.numel() == p.numel()
         lo = None
+        if isinstance(sh, tuple):  # (hi, lo) planes given separately (rows of a stacked operand)
+            sh, lo = sh
+            assert lo.dtype == torch.bfloat16 and lo.is_contiguous() and lo.numel() == p.numel()
         if sh is not None:
             assert sh.dtype == torch.bfloat16 and sh.is_contiguous()
-            if sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
+            if lo is None and sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
                 sh, lo = sh[0], sh[1]
             assert sh.numel() == p.numel()
         arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo))

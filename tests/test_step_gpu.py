@@ -316,7 +316,11 @@ def test_bf16_operand_copies_follow_the_optimizer():
         for n, sh in eng._shadow.items():
             assert torch.equal(sh, params[n].detach().to(torch.bfloat16)), (n, step)
         for n, (_, pl) in eng._wplanes.items():
-            assert torch.equal(pl, ops.split_bf16(params[n].detach())), (n, step)
+            if n == eng.HEADW:  # the two latent heads' weights stacked [2L, H]
+                w = torch.cat([params[h + ".weight"].detach() for h in eng.HEADS], 0)
+            else:
+                w = params[n].detach()
+            assert torch.equal(pl, ops.split_bf16(w.contiguous())), (n, step)
     with torch.no_grad():
         kept = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
         m.__dict__["_eng"] = None  # fresh engine: every operand copy rebuilt from the masters
