@@ -440,34 +440,46 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
         out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = s;
     }
 }
-// Bias only (no condition columns), 16-byte loads: block = 64 column groups (8 bf16 / 4 fp32 columns each) x 4 row
-// groups; a thread walks every 4th row of the chunk with 8 independent loads in flight.
-template <typename TI>
-__global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh, int64_t lddh, int64_t B, int H,
-                                                       float* __restrict__ ws /*[nchunk][H]*/) {
+// 16-byte loads: block = 64 column groups (8 bf16 / 4 fp32 columns each) x 4 row groups; a thread walks every 4th row of
+// its chunk of `rb` rows with 8 independent loads in flight and sums the bias and up to CC condition columns.
+template <typename TI, int CC>
+__global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh, int64_t lddh,
+                                                       const int64_t* __restrict__ cond, int C, int c0, int64_t B, int H,
+                                                       int rb, float* __restrict__ ws /*[nchunk][1+C][H]*/) {
     constexpr int W = 16 / sizeof(TI);  // columns per thread
-    __shared__ float red[4][64 * W];
+    __shared__ float red[4][1 + CC][64 * W];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + cx) * W;
     const int chunk = blockIdx.y;
-    const int64_t b0 = (int64_t)chunk * kBCG_RB, b1 = min(B, b0 + kBCG_RB);
-    float acc[W];
+    const int64_t b0 = (int64_t)chunk * rb, b1 = min(B, b0 + rb);
+    float acc[1 + CC][W];
 #pragma unroll
-    for (int e = 0; e < W; ++e) acc[e] = 0.f;
+    for (int k = 0; k <= CC; ++k)
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[k][e] = 0.f;
     if (col < H) {
-        auto add = [&](const u32x4& v) {
+        auto add = [&](const u32x4& v, int64_t b) {
+            float x[W];
             if constexpr (sizeof(TI) == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] += __builtin_bit_cast(float, v[e] << 16);
-                    acc[2 * e + 1] += __builtin_bit_cast(float, v[e] & 0xffff0000u);
+                    x[2 * e] = __builtin_bit_cast(float, v[e] << 16);
+                    x[2 * e + 1] = __builtin_bit_cast(float, v[e] & 0xffff0000u);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned w = v[e];  // (bit_cast straight from the vector element reads element 0: copy first)
-                    acc[e] += __builtin_bit_cast(float, w);
+                    x[e] = __builtin_bit_cast(float, w);
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc[0][e] += x[e];
+#pragma unroll
+            for (int j = 0; j < CC; ++j) {
+                const float cj = (c0 + j < C) ? (float)cond[b * C + c0 + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < W; ++e) acc[1 + j][e] += x[e] * cj;
             }
         };
         int64_t b = b0 + ry;
@@ -476,36 +488,49 @@ __global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(dh + (b + 4 * u) * lddh + col);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) add(v[u]);
+            for (int u = 0; u < 8; ++u) add(v[u], b + 4 * u);
         }
-        for (; b < b1; b += 4) add(*reinterpret_cast<const u32x4*>(dh + b * lddh + col));
+        for (; b < b1; b += 4) add(*reinterpret_cast<const u32x4*>(dh + b * lddh + col), b);
     }
 #pragma unroll
-    for (int e = 0; e < W; ++e) red[ry][cx * W + e] = acc[e];
+    for (int k = 0; k <= CC; ++k)
+#pragma unroll
+        for (int e = 0; e < W; ++e) red[ry][k][cx * W + e] = acc[k][e];
     __syncthreads();
-    float* out = ws + (int64_t)chunk * H;
-    for (int i = threadIdx.x; i < 64 * W; i += 256) {
-        const int gc = blockIdx.x * 64 * W + i;
-        if (gc < H) out[gc] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    float* out = ws + (int64_t)chunk * (1 + C) * H;
+    for (int i = threadIdx.x; i < (1 + CC) * 64 * W; i += 256) {
+        const int k = i / (64 * W), c = i - k * (64 * W);
+        const int gc = blockIdx.x * 64 * W + c;
+        if (gc >= H) continue;
+        if (k == 0 && c0 != 0) continue;          // the bias row is written by the first condition group only
+        if (k > 0 && c0 + k - 1 >= C) continue;
+        out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
     }
 }
 __global__ __launch_bounds__(256) void bias_cond_stage2(const float* __restrict__ ws, int nchunk, int C, int H,
                                                         float* __restrict__ db, float* __restrict__ dWc, int64_t lddwc,
                                                         const float* __restrict__ alpha_dev) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over (1+C)*H
-    if (i >= (1 + C) * H) return;
-    const int k = i / H, col = i - k * H;
+    // 64 consecutive elements of the [(1+C)*H] result x 4 groups of row chunks, combined through LDS
+    __shared__ float red[4][64];
+    const int lx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lx;  // over (1+C)*H
     const int64_t stride = (int64_t)(1 + C) * H;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 4 <= nchunk; c += 4) {
-        s0 += ws[(c + 0) * stride + i];
-        s1 += ws[(c + 1) * stride + i];
-        s2 += ws[(c + 2) * stride + i];
-        s3 += ws[(c + 3) * stride + i];
+    if (i < (1 + C) * H) {
+        int c = gy;
+        for (; c + 12 < nchunk; c += 16) {
+            s0 += ws[(c + 0) * stride + i];
+            s1 += ws[(c + 4) * stride + i];
+            s2 += ws[(c + 8) * stride + i];
+            s3 += ws[(c + 12) * stride + i];
+        }
+        for (; c < nchunk; c += 4) s0 += ws[c * stride + i];
     }
-    for (; c < nchunk; ++c) s0 += ws[c * stride + i];
-    float s = (s0 + s1) + (s2 + s3);
+    red[gy][lx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy != 0 || i >= (1 + C) * H) return;
+    float s = (red[0][lx] + red[1][lx]) + (red[2][lx] + red[3][lx]);
+    const int k = i / H, col = i - k * H;
     const float alpha = alpha_dev ? *alpha_dev : 1.f;
     s *= alpha;
     if (k == 0) {
@@ -845,7 +870,7 @@ extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t
 }
 
 extern "C" size_t c2_bias_cond_grad_ws(int64_t B, int64_t H, int C) {
-    const int64_t nchunk = (B + kBCG_RB - 1) / kBCG_RB;
+    const int64_t nchunk = (B + 31) / 32;  // the smallest row chunk c2_bias_cond_grad uses
     return (size_t)(nchunk * (1 + C) * H);
 }
 
@@ -858,19 +883,29 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
     C2_CHECK(!dWc || (cond && lddwc >= C), "dWc needs cond");
     if (H == 0) return 0;
     if (!dWc) C = 0;
-    const int nchunk = (int)std::max<int64_t>(1, (B + kBCG_RB - 1) / kBCG_RB);
     hipStream_t st = (hipStream_t)stream;
+    const int W = dh_dtype == C2_F32 ? 4 : 8;
+    const bool vecp = H % W == 0 && lddh % W == 0 && aligned16(dh) && H >= 64 * W;
+    // rows per chunk: 32 for the narrow matrices (more workgroups than 128-row chunks give), 128 otherwise / scalar path
+    const int rb = (vecp && H * (int64_t)((B + 127) / 128) < 256ll * 64 * W) ? 32 : kBCG_RB;
+    const int nchunk = (int)std::max<int64_t>(1, (B + rb - 1) / rb);
+    if (vecp) {
+        dim3 gv((unsigned)((H / W + 63) / 64), nchunk);
+#define BCV_L(TI, CC, c0) \
+    hipLaunchKernelGGL((bias_stage1_vec<TI, CC>), gv, dim3(256), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, rb, ws)
+        for (int c0 = 0; c0 == 0 || c0 < C; c0 += 4) {
+            const int left = C - c0;
+            if (dh_dtype == C2_F32) {
+                if (left <= 0) BCV_L(float, 0, c0); else BCV_L(float, 4, c0);
+            } else {
+                if (left <= 0) BCV_L(bf16_t, 0, c0); else BCV_L(bf16_t, 4, c0);
+            }
+        }
+#undef BCV_L
+    } else {
     dim3 g1((unsigned)((H + 127) / 128), nchunk);
 #define BCG_L(TI, CC, c0) \
     hipLaunchKernelGGL((bias_cond_stage1<TI, CC>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, ws)
-    const int W = dh_dtype == C2_F32 ? 4 : 8;
-    if (C == 0 && H % W == 0 && lddh % W == 0 && aligned16(dh) && H >= 1024) {
-        dim3 gv((unsigned)((H / W + 63) / 64), nchunk);
-        if (dh_dtype == C2_F32)
-            hipLaunchKernelGGL(bias_stage1_vec<float>, gv, dim3(256), 0, st, (const float*)dh, lddh, B, (int)H, ws);
-        else
-            hipLaunchKernelGGL(bias_stage1_vec<bf16_t>, gv, dim3(256), 0, st, (const bf16_t*)dh, lddh, B, (int)H, ws);
-    } else
     for (int c0 = 0; c0 == 0 || c0 < C; c0 += kBCG_MAXC) {
         const int left = C - c0;
         if (dh_dtype == C2_F32) {
@@ -884,8 +919,9 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
         }
     }
 #undef BCG_L
+    }
     const int n2 = (int)((1 + C) * H);
-    hipLaunchKernelGGL(bias_cond_stage2, dim3((n2 + 255) / 256), dim3(256), 0, st, ws, nchunk, C, (int)H, db, dWc,
+    hipLaunchKernelGGL(bias_cond_stage2, dim3((n2 + 63) / 64), dim3(256), 0, st, ws, nchunk, C, (int)H, db, dWc,
                        lddwc, alpha_dev);
     C2_LAUNCH_CHECK();
     return 0;
