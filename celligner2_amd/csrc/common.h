@@ -61,6 +61,11 @@ __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; 
 template <>
 __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// log(1 + x) of a count (x >= 0) on v_log_f32 (1 ulp): 1 + x is a normal number >= 1, so none of libm's range and
+// denormal handling is needed -- the library logf costs ~30 VALU instructions per element and made the batch gather
+// VALU-bound.
+__device__ __forceinline__ float log1p_count(float x) { return __builtin_amdgcn_logf(1.0f + x) * 0.6931471805599453f; }
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

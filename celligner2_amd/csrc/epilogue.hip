@@ -36,7 +36,7 @@ __global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int
             f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
             if (apply_log) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = logf(1.0f + v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = log1p_count(v[e]);
             }
             TO* o = out + r * ldo + c;
             if (sizeof(TO) == 4) {
@@ -54,7 +54,7 @@ __global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int
              i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t r = i / cols, c = i - r * cols;
             float v = x[r * ldx + c];
-            if (apply_log) v = logf(1.0f + v);
+            if (apply_log) v = log1p_count(v);
             st_from_f32<TO>(out + r * ldo + c, v);
         }
     }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             if (xin_out) {
                 f32x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = apply_log ? logf(1.0f + v[e]) : v[e];
+                for (int e = 0; e < 4; ++e) t[e] = apply_log ? log1p_count(v[e]) : v[e];
                 TX* dst = xin_out + r * ldxin + c * 4;
                 if (sizeof(TX) == 2 && vec_xin) {
                     u32x2 pk;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         for (int64_t c = threadIdx.x; c < G; c += 256) {
             const float v = xs[c];
             if (xd) xd[c] = v;
-            if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, apply_log ? logf(1.0f + v) : v);
+            if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, apply_log ? log1p_count(v) : v);
             if (copy_good) goodloc_out[r * G + c] = goodloc[src * G + c];
         }
     }
