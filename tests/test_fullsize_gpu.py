@@ -1,0 +1,108 @@
+"""The benchmark configuration itself (C4: 4096 cells x 19 000 genes, hidden [1024, 512], latent 64, NB + MMD) is
+too large for the numpy oracle, so at full size the step is checked through properties that do not depend on the
+size: bit-level determinism (no atomics anywhere), invariance under a permutation of the batch rows, the
+resident-row path (the loss kernel reads the dataset rows through the row index) against gathered copies, linearity
+of the backward pass in the loss weights, and agreement of the bf16-operand mode with the fp32 mode (which is
+pinned to the reference at 1e-4 on the small fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G, HIDDEN, L, C, B, N = 19000, [1024, 512], 64, 3, 4096, 6144
+
+
+@pytest.fixture(scope="module")
+def world():
+    from celligner2_amd.dataset import DeviceDataset
+    from celligner2_amd.model import Celligner2
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    gene = torch.exp(torch.randn(1, G, device=DEV, generator=g) * 1.5 + 1.5)
+    depth = torch.empty(N, 1, device=DEV).uniform_(0.5, 2.0, generator=g)
+    X = torch.poisson(depth * gene, generator=g)
+    good = torch.rand(N, G, device=DEV, generator=g) > 0.005
+    cond = torch.zeros(N, C, dtype=torch.int64, device=DEV)
+    cond[torch.arange(N, device=DEV), torch.randint(0, C, (N,), device=DEV, generator=g)] = 1
+    data = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None)
+    torch.manual_seed(11)
+    models = {}
+    for prec in ("bf16", "fp32"):
+        torch.manual_seed(11)
+        models[prec] = Celligner2(G, HIDDEN, L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=1.0,
+                                  precision=prec).to(DEV).train()
+    models["fp32"].load_state_dict(models["bf16"].state_dict())
+    idx = torch.randperm(N, device=DEV, generator=g)[:B]
+    eps = torch.randn(B, L, device=DEV, generator=g)
+    return data, models, idx, eps
+
+
+def _step(model, batch, eps, weights=(1.0, 1e-3, 1.0, 1.0)):
+    model._forced_noise = dict(eps=eps, masks={})
+    for p in model.parameters():
+        p.grad = None
+    total, v = model.forward_total(weights, **batch)
+    total.backward(gradient=torch.ones((), device=DEV))
+    model._engine().check_status()
+    return v.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_deterministic_and_resident_rows_equal_gathered_copies(world):
+    data, models, idx, eps = world
+    m = models["bf16"]
+    res = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=True)
+    v1, g1 = _step(m, dict(res), eps)
+    v2, g2 = _step(m, dict(res), eps)
+    assert torch.equal(v1, v2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n  # split reductions are fixed-order slabs: bit-identical runs
+    cop = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=False)
+    assert "x" in cop and "x_full" in res and "x" not in res
+    v3, g3 = _step(m, dict(cop), eps)
+    assert torch.equal(v1, v3)
+    for n in g1:
+        assert torch.equal(g1[n], g3[n]), n
+
+
+def test_row_permutation_invariance(world):
+    data, models, idx, eps = world
+    m = models["bf16"]
+    perm = torch.randperm(B, device=DEV)
+    v1, g1 = _step(m, dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True)), eps)
+    v2, g2 = _step(m, dict(data.gather(idx[perm], torch.bfloat16, True, nb_const=True, resident_rows=True)), eps[perm])
+    assert torch.allclose(v1, v2, rtol=2e-5, atol=1e-6), (v1, v2)
+    for n in g1:
+        assert _l2(g2[n], g1[n]) < 2e-4, (n, _l2(g2[n], g1[n]))  # only the summation order over the batch differs
+
+
+def test_backward_is_linear_in_the_loss_weights(world):
+    data, models, idx, eps = world
+    m = models["bf16"]
+    batch = dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True))
+    _, ga = _step(m, dict(batch), eps, (1.0, 0.0, 1.0, 1.0))
+    _, gb = _step(m, dict(batch), eps, (1.0, 2.0, 1.0, 1.0))
+    _, gm = _step(m, dict(batch), eps, (1.0, 1.0, 1.0, 1.0))
+    for n in ga:
+        mid = 0.5 * (ga[n].double() + gb[n].double())
+        assert _l2(gm[n], mid) < 5e-3, (n, _l2(gm[n], mid))  # bf16 rounding of the back-propagated signal only
+
+
+def test_bf16_mode_agrees_with_fp32_mode(world):
+    data, models, idx, eps = world
+    batch32 = dict(data.gather(idx, torch.float32, True, nb_const=True, resident_rows=True))
+    batch16 = dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True))
+    v32, g32 = _step(models["fp32"], batch32, eps)
+    v16, g16 = _step(models["bf16"], batch16, eps)
+    assert torch.allclose(v16, v32, rtol=1e-2, atol=1e-4), (v16, v32)
+    for n in g32:
+        assert _l2(g16[n], g32[n]) < 1e-2, (n, _l2(g16[n], g32[n]))  # the north_star bound of bf16 mode
+    # softmax means of the decoder sum to one per cell (reconstructLatent), at full width
+    with torch.no_grad():
+        z, _ = models["fp32"].get_latent(data.data[idx[:64]], data.conditions[idx[:64]], mean=True)
+        rec, _ = models["fp32"].reconstructLatent(z, data.conditions[idx[:64]])
+    assert torch.allclose(rec.sum(1), torch.ones(64, device=DEV), atol=1e-4)
