@@ -161,10 +161,19 @@ def main():
         trainer.on_iteration(next(stream))
     sync()
     ops.PROFILE_GEMM = []  # (flops, start_event, end_event) of every gene-width GEMM launch in the timed region
+    prof_host = None
+    if os.environ.get("C2_BENCH_CPROFILE"):  # developer aid: cProfile of the host launch path of the timed steps
+        import cProfile
+        prof_host = cProfile.Profile()
+        prof_host.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.on_iteration(next(stream))
     t_host = time.perf_counter() - t0  # the launch path alone (the GPU queue drains in sync())
+    if prof_host is not None:
+        import pstats
+        prof_host.disable()
+        pstats.Stats(prof_host, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None

@@ -307,22 +307,34 @@ class Celligner2(nn.Module):
             betaclass=float(self.betaclass), use_ln=bool(self.use_ln), use_bn=bool(self.use_bn))
 
     def _engine(self) -> StepEngine:
+        """The step engine bound to this module's current parameters.  Called on every forward, so the check that the
+        cached engine is still valid walks a prepared list of (module, slot, parameter) instead of named_parameters()
+        (0.5 ms of Python per call): a replaced, moved or re-typed parameter, a changed option or precision rebuilds."""
+        eng = self.__dict__["_eng"]
+        cfg = self._cfg()
+        if eng is not None and eng.cfg == cfg and eng.precision == self.precision:
+            slots = self.__dict__["_eng_slots"]
+            if (all(m._parameters.get(k) is p and p.device == eng.dev for m, k, p in slots)
+                    and len(slots) == self.__dict__["_eng_nparam"]
+                    and all(m.running_mean is not None and m.running_mean.device == eng.dev for m in eng.bn.values())):
+                return eng
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
         if dev.type != "cuda":
             raise ops.L.C2Error("celligner2_amd.Celligner2 computes only on an MI355X: move the module to the GPU "
                                 "(model.cuda()); there is no CPU path")
-        eng = self.__dict__["_eng"]
-        cfg = self._cfg()
         bns = {n: m for n, m in self.named_modules() if isinstance(m, _BatchNorm)} if self.use_bn else {}
-        stale = (eng is None or eng.dev != dev or eng.cfg != cfg or eng.precision != self.precision
-                 or any(eng.p.get(n) is not p for n, p in params.items()) or len(eng.p) != len(params)
-                 or any(eng.bn.get(n) is not m or m.running_mean.device != dev for n, m in bns.items()))
-        if stale:
-            eng = StepEngine(cfg, params, self.precision, bn_modules=bns)
-            if self.world is not None:
-                self.world.attach(eng)
-            self.__dict__["_eng"] = eng
+        eng = StepEngine(cfg, params, self.precision, bn_modules=bns)
+        if self.world is not None:
+            self.world.attach(eng)
+        self.__dict__["_eng"] = eng
+        slots = []
+        for mod in self.modules():
+            for k, p in mod._parameters.items():
+                if p is not None:
+                    slots.append((mod, k, p))
+        self.__dict__["_eng_slots"] = slots
+        self.__dict__["_eng_nparam"] = len(slots)
         self.__dict__["_param_names"] = list(params.keys())
         self.__dict__["_param_list"] = list(params.values())
         return eng
