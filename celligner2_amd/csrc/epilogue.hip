@@ -610,13 +610,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const int64_t* __restrict__ idx, float* __restrict__ x_out, uint8_t* __restrict__ goodloc_out,
     float* __restrict__ sf_out, int64_t* __restrict__ cond_out, int64_t* __restrict__ classes_out,
     TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin,
-    const float* __restrict__ rowconst, float* __restrict__ rowconst_out) {
+    const float* __restrict__ rowconst, float* __restrict__ rowconst_out, int32_t* __restrict__ idx32_out,
+    int64_t n, int64_t n_pad) {
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
+    if (idx32_out && threadIdx.x == 0) {
+        idx32_out[r] = (int32_t)src;
+        if (r == n - 1)
+            for (int64_t q = n; q < n_pad; ++q) idx32_out[q] = (int32_t)src;  // padding: any valid row
+    }
     const float* xs = X + src * G;
     float* xd = x_out ? x_out + r * G : nullptr;
     const bool copy_good = goodloc && goodloc_out;
-    if (vec_ok) {
+    if (!xd && !xin_out && !copy_good) {
+        // nothing per gene: the consumers read the resident rows themselves
+    } else if (vec_ok) {
         const int64_t gv = G >> 2;
         auto emit = [&](int64_t c, const f32x4& v, unsigned gm) {
             if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
@@ -973,10 +981,11 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
                               const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
                               float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
                               int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
-                              const float* rowconst, float* rowconst_out, void* stream) {
+                              const float* rowconst, float* rowconst_out, int32_t* idx32_out, int64_t idx32_len,
+                              void* stream) {
     C2_CHECK(X && idx, "null pointer");
     C2_CHECK(!rowconst || rowconst_out, "rowconst_out missing");
-    C2_CHECK(x_out || xin_out, "nothing to write: x_out and xin_out are both NULL");
+    C2_CHECK(!idx32_out || idx32_len >= n, "idx32_out shorter than the batch");
     C2_CHECK(!sizefactor || sf_out, "sf_out missing");
     C2_CHECK(!cond || cond_out, "cond_out missing");
     C2_CHECK(!classes || classes_out, "classes_out missing");
@@ -989,11 +998,11 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
     if (xin_out && xin_dtype == C2_BF16)
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out);
+                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out);
+                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len);
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -18,10 +18,16 @@ struct GemmArgs {
     int M, N, R, r_per_split;
     const void* A_lo;  // C2_BF16X3P: the low bf16 planes of the two operands (same layout / leading dimension)
     const void* B_lo;
+    // Row-indexed operand (a batch read in place from a resident matrix, no gathered copy):
+    //   layout 0 (forward): output row m reads row rows[m] of A;  layout 2 (wgrad): reduction index r reads row rows[r]
+    //   of B.  int32, readable up to the reduction length rounded up to 64 (layout 2).  NULL: plain operands.
+    const int32_t* rows;
 };
 
 // Block-tile edge gemm_wide.hip uses for this problem (256 or 128), or 0 when it does not take it.
 int wide_tile(int dtype, const GemmArgs& a);
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream);
+// Row-indexed instances (256x256 tile, bf16, layouts 0 and 2 only); 0 = launched, 3 = shape not supported.
+int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream);
 
 }  // namespace c2

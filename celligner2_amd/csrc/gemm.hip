@@ -426,12 +426,51 @@ extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t 
     C2_CHECK(!(bias && nslab != 1), "bias needs nslab == 1");
     C2_CHECK(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
     if (M == 0 || N == 0) return 0;
-    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr};
+    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr, nullptr};
     if (dtype == C2_BF16X3P) {
         a.A_lo = (const bf16_t*)A + M * lda;
         a.B_lo = (const bf16_t*)W + N * ldw;
     }
     C2_CHECK(gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_rows, const int32_t* row_index, const void* W,
+                                  int64_t ldw, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
+                                  int64_t slab_stride, const float* bias, void* stream) {
+    C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
+    C2_CHECK(A_full && row_index && W && Y, "null pointer");
+    C2_CHECK(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
+    C2_CHECK(a_rows >= 1 && a_rows * lda < (1ll << 31), "resident matrix too large for 32-bit element offsets");
+    C2_CHECK(!(bias && nslab != 1), "bias needs nslab == 1");
+    C2_CHECK(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs a{A_full, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr, row_index};
+    int64_t per = (a.R + nslab - 1) / nslab;
+    a.r_per_split = (int)((per + 63) / 64 * 64);
+    C2_CHECK(launch_gemm_wide_rows(0, a, nslab, (hipStream_t)stream) == 0,
+             "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): gather the rows instead");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64_t lda, int64_t a_rows,
+                                    const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw,
+                                    int nslab, int64_t slab_stride, const float* alpha_dev, void* stream) {
+    C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
+    C2_CHECK(dY && A_full && row_index && dW, "null pointer");
+    C2_CHECK(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
+    C2_CHECK(a_rows >= 1 && a_rows * lda < (1ll << 31), "resident matrix too large for 32-bit element offsets");
+    C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
+    if (N == 0 || K == 0) return 0;
+    // C[n][k] = sum_m dY[m][n] A[rows[m]][k]: A-op = dY (XC over n), B-op = A_full (XC over k, reduction rows indexed)
+    GemmArgs a{dY, A_full, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr,
+               row_index};
+    int64_t per = (a.R + nslab - 1) / nslab;
+    a.r_per_split = (int)((per + 63) / 64 * 64);
+    C2_CHECK(launch_gemm_wide_rows(2, a, nslab, (hipStream_t)stream) == 0,
+             "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): gather the rows instead");
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -445,7 +484,7 @@ extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int6
     C2_CHECK(nslab == 1 || slab_stride >= M * ldda, "slab_stride too small");
     if (M == 0 || K == 0) return 0;
     // C[m][k] = sum_n dY[m][n] W[n][k]:  A-op = dY (RC over n), B-op = W ([n][k]: XC, output index k contiguous)
-    GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0, nullptr, nullptr};
+    GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0, nullptr, nullptr, nullptr};
     if (dtype == C2_BF16X3P) {
         a.A_lo = (const bf16_t*)dY + M * lddy;
         a.B_lo = (const bf16_t*)W + N * ldw;
@@ -464,7 +503,7 @@ extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int6
     C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
     if (N == 0 || K == 0) return 0;
     // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
-    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr};
+    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
     if (dtype == C2_BF16X3P) {
         a.A_lo = (const bf16_t*)dY + M * lddy;
         a.B_lo = (const bf16_t*)A + M * lda;

@@ -176,8 +176,12 @@ __device__ __forceinline__ void wait_loads(int c) {
 // Ring of NSLOT = 2*D + 1 operand-tile slots: while K-tile T is multiplied, the loads of tiles T+1 .. T+D-1 and A of
 // T+D are in flight or landed.  D = 2 for the 256x256 tile (5 x 32 KB), D = 4 for the 128x128 tile (9 x 16 KB): its
 // K-step is short (16 MFMAs per wave), so the ~1 us LDS-DMA round trip needs more tiles ahead of it.
-template <bool A_RC, bool B_RC, int NW>
+// IDX: 0 plain operands; 1 the rows of the (RC) A operand are read through a.rows (forward of a batch that lives in a
+// resident matrix); 2 the k-rows of the (XC) B operand are (its weight gradient).  The per-lane DMA source address
+// carries the row: for IDX 1 once per block, for IDX 2 per K-tile from eight wave-uniform (scalar) index loads.
+template <bool A_RC, bool B_RC, int NW, int IDX = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    static_assert(IDX == 0 || (IDX == 1 && A_RC) || (IDX == 2 && !B_RC), "row index on an RC A or an XC B operand");
     constexpr int BX = 32 * NW;             // block tile edge: 256 or 128
     constexpr int D = NW == 8 ? 2 : 4;
     constexpr int NSLOT = 2 * D + 1;
@@ -220,8 +224,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     const int nt = a.A_lo ? 3 * nt1 : nt1;          // bf16x3: segments (hi,hi) (hi,lo) (lo,hi)
 
     // uniform tile bases (scalar registers) + 32-bit per-lane offsets
-    const int64_t offA = A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0;
-    const int64_t offB = B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0;
+    const int64_t offA = IDX == 1 ? (int64_t)rbeg : (A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0);
+    const int64_t offB = IDX == 2 ? (int64_t)n0 : (B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0);
     const bf16_t* Ah = reinterpret_cast<const bf16_t*>(a.A) + offA;
     const bf16_t* Bh = reinterpret_cast<const bf16_t*>(a.B) + offB;
     const bf16_t* Al = reinterpret_cast<const bf16_t*>(a.A_lo) + offA;
@@ -233,7 +237,35 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         vob[j] = stage_offset<B_RC, BX>(j, a.ldb, n0, a.N, wave, lane);
     }
     const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
-    const int64_t stepB = B_RC ? BK : (int64_t)BK * a.ldb;
+    const int64_t stepB = IDX == 2 ? 0 : (B_RC ? BK : (int64_t)BK * a.ldb);
+    if (IDX == 1) {  // row part of A's offsets: the indexed row instead of the tile row (edge rows re-read the last row)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 8 * (4 * wave + j) + (lane >> 3);
+            const int x = min(row, a.M - 1 - m0);
+            voa[j] += (a.rows[m0 + x] - x) * (int)a.lda;
+        }
+    }
+    // IDX 2: vob[j] = rows[k-row] * ldb + xob[j]; the DMA instruction j of this wave covers k-rows 8*wave + 2j + {0,1}
+    int xob[4];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int kr[8];  // the wave's eight row indices of the B tile that is issued next
+    auto load_krows = [&](int t) {
+        const int32_t* rp = a.rows + rbeg + t * BK + 8 * wave_u;  // wave-uniform address: scalar loads
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kr[q] = rp[q];
+    };
+    auto set_vob = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vob[j] = ((lane >> 5) ? kr[2 * j + 1] : kr[2 * j]) * (int)a.ldb + xob[j];
+    };
+    if (IDX == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * wave + 2 * j + (lane >> 5);
+            xob[j] = vob[j] - k * (int)a.ldb;  // the column part stage_offset<XC> computed
+        }
+    }
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -272,6 +304,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     };
     auto issueB = [&](int slot, int q) {
         if ((dbg & 1) || segB >= nseg) return;
+        if (IDX == 2 && q <= 0) {  // (generic path: index loads not prefetched)
+            load_krows(tB);
+            set_vob();
+        }
         char* dst = smem + slot * TILE_BYTES;
         if (tB < nfull) {
             if (q != 1) stage_dma<0, 2>(pB, vob, dst, wave);
@@ -303,7 +339,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
 #if C2_GEMM_DBG & 16
     unsigned long long wait_clk = 0, bar_clk = 0;
 #endif
+    if (IDX == 2 && nfast > 0) load_krows(tB);
     for (; T < nfast; ++T) {
+        if (IDX == 2) {
+            set_vob();                                // offsets of the B tile issued in this iteration (tile tB) ...
+            load_krows(min(tB + 1, nt1 - 1));         // ... and the scalar index loads of the next one
+        }
         // loads 2T and 2T+1 must have landed; the 2D-3 newer ones stay in flight
 #if C2_GEMM_DBG & 16
         const unsigned long long w0 = clock64();
@@ -462,6 +503,26 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
         hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     else
         hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
+}
+
+int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+    using namespace wide;
+    if (!a.rows || a.A_lo || (layout != 0 && layout != 2) || wide_tile(C2_BF16, a) != 256) return 3;
+    constexpr int NW = 8, BX = 256;
+    constexpr int LDS = 5 * BX * BK * 2;
+    const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;
+    const dim3 grid(tiles_m * tiles_n * nslab);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, true, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    if (layout == 0)
+        hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW, 1>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW, 2>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
+    return 0;
 }
 
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {

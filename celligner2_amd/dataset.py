@@ -131,15 +131,33 @@ class DeviceDataset:
             c = self._nb_row_const = ops.nb_row_const(self.data, self.goodloc)
         return c
 
-    def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None, nb_const=False, resident_rows=False):
+    def xin_resident(self, apply_log):
+        """[n, G] bf16: the encoder input of EVERY resident row (log(1+x) or x), converted once per dataset like the
+        size factors (3.8 GB for 100k x 19k of 288 GB).  A batch is then rows of this matrix, read in place by the
+        row-indexed GEMMs (c2_linear_fwd_rows / c2_linear_wgrad_rows): no per-step copy of the encoder input."""
+        cache = self.__dict__.setdefault("_xin_res", {})
+        t = cache.get(bool(apply_log))
+        if t is None:
+            t = torch.empty((self.n, self.G), dtype=torch.bfloat16, device=self.device)
+            for s in range(0, self.n, 16384):
+                ops.prep_input(self.data[s:s + 16384], t[s:s + 16384], bool(apply_log))
+            cache[bool(apply_log)] = t
+        return t
+
+    def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None, nb_const=False, resident_rows=False,
+               resident_xin=False):
         """Batch dict for rows `idx` (int64 device tensor): the keys custom_collate would produce
         (trainers/celligner2/_utils.py:188-225) plus `xin`, the encoder input written by the same kernel.
 
         resident_rows=True (needs xin_dtype): x and goodloc are NOT copied; the batch carries the resident matrices
         and the row index instead (`x_full`, `goodloc_full`, `row_index`) and the NB loss kernel reads the rows
-        where they live -- the gather then moves 6 instead of 12 bytes per gene."""
+        where they live -- the gather then moves 6 instead of 12 bytes per gene.
+        resident_xin=True (with resident_rows, bf16 input, G * n < 2^31): the encoder input is not written either:
+        the batch carries `xin_full` (xin_resident) and `row_index32`, and only the per-row scalars are gathered."""
         n = idx.numel()
         resident_rows = resident_rows and xin_dtype is not None
+        resident_xin = (resident_xin and resident_rows and xin_dtype == torch.bfloat16 and self.n * self.G < 2 ** 31
+                        and n % 8 == 0)
         bufs = bufs if bufs is not None else {}
 
         def get(key, shape, dtype):
@@ -159,8 +177,11 @@ class DeviceDataset:
             cond_o = out["batch"] = get("batch", (n, self.conditions.shape[1]), torch.int64)
         if self.predictor_keys:
             cls_o = out["classes"] = get("classes", (n, self.predictors.shape[1]), torch.int64)
-        xin = None
-        if xin_dtype is not None:
+        xin = idx32 = None
+        if resident_xin:
+            out["xin_full"] = self.xin_resident(apply_log)
+            idx32 = out["row_index32"] = get("row_index32", ((n + 63) // 64 * 64,), torch.int32)
+        elif xin_dtype is not None:
             xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
         rc = rc_o = None
         if nb_const:
@@ -168,7 +189,8 @@ class DeviceDataset:
             out["lgx1"] = rc_o
         ops.gather_rows(self.data, self.goodloc, self.size_factors, self.conditions if cond_o is not None else None,
                         self.predictors if cls_o is not None else None, idx, out.get("x"), out.get("goodloc"),
-                        out["sizefactor"], cond_o, cls_o, xin, apply_log, rowconst=rc, rowconst_out=rc_o)
+                        out["sizefactor"], cond_o, cls_o, xin, apply_log, rowconst=rc, rowconst_out=rc_o,
+                        idx32_out=idx32)
         return out
 
 

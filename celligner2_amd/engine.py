@@ -340,6 +340,11 @@ class StepEngine:
     def _linear_slabs(self, key, a, wname, B):
         w = self.weight(wname)
         N, K = w.shape
+        if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): the batch is read in place
+            ns = ops.pick_nslab(B, N, K, w.dtype, self.x3)
+            y = self.buf(key + ".Y", (ns, B, N))
+            ops.linear_fwd_rows(a[0], a[1], B, w, y, nslab=ns)
+            return y
         a2, w2, pl = self._pair(a, w, B, N, K, wy=wname)
         ns = ops.pick_nslab(B, N, K, a.dtype, self.x3, planes=pl)
         y = self.buf(key + ".Y", (ns, B, N))
@@ -352,6 +357,16 @@ class StepEngine:
         if g is None:
             g = self.gbuf(name)
         N, K = g.shape
+        if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): gene-width by construction
+            if not self._wgrad_two_part(dy, a, g, alpha):
+                ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
+                if ns == 1:
+                    self._wg(dy, a, g, alpha=alpha)
+                else:
+                    slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
+                    self._wg(dy, a, slabs, nslab=ns, alpha=alpha)
+                    ops.sum_slabs(slabs, g)
+            return
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
         if not pl and self._wgrad_two_part(dy, a, g, alpha):
             return
@@ -362,6 +377,16 @@ class StepEngine:
             slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
             ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
+
+    @staticmethod
+    def _wg(dy, a, out, nslab=1, alpha=None, cols=None):
+        """Weight-gradient launch for a plain activation matrix or a (resident matrix, row index) pair; cols: column
+        slice of the activation."""
+        if isinstance(a, tuple):
+            af = a[0] if cols is None else a[0][:, cols]
+            ops.linear_wgrad_rows(dy, af, a[1], out, nslab=nslab, alpha=alpha)
+        else:
+            ops.linear_wgrad(dy, a if cols is None else a[:, cols], out, nslab=nslab, alpha=alpha)
 
     def _wgrad_two_part(self, dy, a, g, alpha):
         """A gene-width weight gradient whose 256x256 tiles number a little more than a multiple of the 256 CUs
@@ -382,19 +407,19 @@ class StepEngine:
         tiles2 = ((rest + 255) // 256) * per
         ns = max(1, min(16, 256 // tiles2, M // 256))
         if by_rows:
-            ops.linear_wgrad(dy[:, :cut], a, g[:cut], alpha=alpha)
+            self._wg(dy[:, :cut], a, g[:cut], alpha=alpha)
             slabs = self.buf(f"wgrad.strip.{ns}x{rest}x{K}", (ns, rest, K))
-            ops.linear_wgrad(dy[:, cut:], a, slabs, nslab=ns, alpha=alpha)
+            self._wg(dy[:, cut:], a, slabs, nslab=ns, alpha=alpha)
             ops.sum_slabs(slabs, g[cut:])
         else:
-            ops.linear_wgrad(dy, a[:, :cut], g[:, :cut], alpha=alpha)
+            self._wg(dy, a, g[:, :cut], alpha=alpha, cols=slice(0, cut))
             slabs = self.buf(f"wgrad.strip.{ns}x{N}x{rest}", (ns, N, rest))
-            ops.linear_wgrad(dy, a[:, cut:], slabs, nslab=ns, alpha=alpha)
+            self._wg(dy, a, slabs, nslab=ns, alpha=alpha, cols=slice(cut, None))
             ops.sum_slabs_2d(slabs, g[:, cut:])
         return True
 
     def _block_fwd(self, blk, a, cond, masks, train, save):
-        B = a.shape[0]
+        B = a.shape[0] if not isinstance(a, tuple) else self._B
         y = self._linear_slabs(blk.name, a, blk.w, B)
         H = y.shape[2]
         act = self.buf(blk.name + ".act", (B, H), blk.out_t)
@@ -456,7 +481,7 @@ class StepEngine:
 
     def _block_bwd(self, blk, dact, a_in, cond, masks, need_da, out_slabs=None, extra=None, extra_scale=None):
         """dact: fp32 [B,H] or slabs.  Returns the slabs of d(a_in) (or None)."""
-        B = a_in.shape[0]
+        B = a_in.shape[0] if not isinstance(a_in, tuple) else self._B
         H = self.p[blk.w].shape[0]
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if p > 0 else None
@@ -520,7 +545,12 @@ class StepEngine:
         cfg = self.cfg
         x = batch.get("x")  # None: the rows live in the resident matrices (x_full / goodloc_full / row_index)
         cond = batch.get("batch")
-        B, G = x.shape if x is not None else batch["xin"].shape
+        if x is not None:
+            B, G = x.shape
+        elif batch.get("xin") is not None:
+            B, G = batch["xin"].shape
+        else:
+            B, G = batch["row_index"].numel(), batch["xin_full"].shape[1]
         Bn = B * self.world_size
         inv_B = 1.0 / Bn
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
@@ -532,7 +562,18 @@ class StepEngine:
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
         pre = batch.get("xin")  # already produced by the device-resident gather
-        if pre is not None and pre.dtype == xt:
+        rows = None
+        if pre is None and batch.get("xin_full") is not None:
+            # the encoder input stays in the resident bf16 matrix: the first layer's GEMMs read it through the row index
+            xf, r32 = batch["xin_full"], batch["row_index32"]
+            H0 = self.p[self.enc[0].w].shape[0]
+            if not (xt == torch.bfloat16 and xf.dtype == torch.bfloat16 and B % 8 == 0
+                    and ops.gemm_tile(xt, B, H0, G) == 256 and ops.gemm_tile(xt, H0, G, B) == 256):
+                raise ValueError("xin_full / row_index32 need bf16 mode and a first layer the 256x256 GEMM takes; "
+                                 "gather the encoder input instead (DeviceDataset.gather(resident_xin=False))")
+            rows = (xf, r32)
+            xin = None
+        elif pre is not None and pre.dtype == xt:
             xin = pre
         elif x is None:
             raise ValueError("a batch without x needs xin in the encoder's operand dtype")
@@ -543,7 +584,7 @@ class StepEngine:
             xin = x
         self._xin = xin
         # ---- encoder
-        a = xin
+        a = xin if rows is None else rows
         self._enc_in = []
         for blk in self.enc:
             self._enc_in.append(a)

@@ -410,15 +410,18 @@ class Celligner2(nn.Module):
 
     # ------------------------------------------------------------------ the reference's API
     def forward(self, x=None, batch=None, sizefactor=None, classes=None, weight=None, goodloc=None,
-                main_dataset=None, xin=None, lgx1=None, x_full=None, goodloc_full=None, row_index=None):
+                main_dataset=None, xin=None, lgx1=None, x_full=None, goodloc_full=None, row_index=None,
+                xin_full=None, row_index32=None):
         """The reference's forward (celligner2.py:259-374).  Extra keywords, all produced by DeviceDataset.gather:
         xin (encoder input already transformed), lgx1 (data-only NB term), and x_full / goodloc_full / row_index
-        (the batch's counts are rows `row_index` of the resident matrices; x itself is then not needed)."""
+        (the batch's counts are rows `row_index` of the resident matrices; x itself is then not needed), and
+        xin_full / row_index32 instead of xin (the encoder input is read in place from the resident bf16 matrix)."""
         if x is None:
-            if x_full is None or row_index is None or xin is None or sizefactor is None:
-                raise ValueError("forward needs x, or x_full + row_index + xin + sizefactor from a resident dataset")
-            dev = xin.device
-            B = xin.shape[0]
+            if x_full is None or row_index is None or (xin is None and xin_full is None) or sizefactor is None:
+                raise ValueError("forward needs x, or x_full + row_index + xin (or xin_full + row_index32) + sizefactor "
+                                 "from a resident dataset")
+            dev = x_full.device
+            B = row_index.numel()
             bt = dict(x=None, x_full=x_full, row_index=row_index,
                       goodloc_full=goodloc_full if goodloc_full is not None else torch.ones_like(x_full, dtype=torch.bool),
                       sizefactor=sizefactor.reshape(B).float().contiguous())
@@ -442,6 +445,10 @@ class Celligner2(nn.Module):
             bt["classes"] = classes
         if xin is not None:
             bt["xin"] = xin
+        if xin_full is not None:
+            if row_index32 is None:
+                raise ValueError("xin_full needs row_index32")
+            bt["xin_full"], bt["row_index32"] = xin_full, row_index32
         if lgx1 is not None:  # per-row sum of goodloc*lgamma(x+1), precomputed by a resident dataset
             bt["lgx1"] = lgx1.float().contiguous()
         eps, masks = self._draw_noise(B, classes is not None, dev)

@@ -114,6 +114,43 @@ def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
     return y
 
 
+def _rows_arg(a_full, rows, need):
+    assert a_full.dtype == torch.bfloat16 and a_full.dim() == 2 and a_full.stride(1) == 1
+    assert rows.dtype == torch.int32 and rows.is_contiguous() and rows.numel() >= need
+
+
+def linear_fwd_rows(a_full, rows, M, w, y, bias=None, nslab=1):
+    """y[s] = a_full[rows[:M]] @ w.T (+bias): the batch is read in place from the resident bf16 matrix."""
+    L.require_gpu(a_full, rows, w, y)
+    _rows_arg(a_full, rows, M)
+    N, K = w.shape
+    assert w.dtype == torch.bfloat16 and a_full.shape[1] == K and y.dtype == torch.float32
+    y2 = y if y.dim() == 2 else y[0]
+    assert tuple(y2.shape) == (M, N) and ((y.dim() == 3 and y.shape[0] == nslab) or nslab == 1)
+    ss = y.stride(0) if y.dim() == 3 else 0
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_fwd_rows(ptr(a_full), a_full.stride(0), a_full.shape[0], ptr(rows), ptr(w), _row_major(w, "w"),
+                                     M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
+    return y
+
+
+def linear_wgrad_rows(dy, a_full, rows, dw, nslab=1, alpha=None):
+    """dw[s] = alpha * dy.T @ a_full[rows[:M]]; rows must be readable up to M rounded up to 64."""
+    L.require_gpu(dy, a_full, rows, dw)
+    M, N = dy.shape
+    _rows_arg(a_full, rows, (M + 63) // 64 * 64)
+    K = a_full.shape[1]
+    assert dy.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    d2 = dw if dw.dim() == 2 else dw[0]
+    assert tuple(d2.shape) == (N, K) and ((dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1)
+    ss = dw.stride(0) if dw.dim() == 3 else 0
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_wgrad_rows(ptr(dy), _row_major(dy, "dy"), ptr(a_full), a_full.stride(0), a_full.shape[0],
+                                       ptr(rows), M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha),
+                                       stream()))
+    return dw
+
+
 def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     """da[s] = alpha * dy @ w.   dy [M,N], w [N,K], da [M,K] or [nslab,M,K]."""
     L.require_gpu(dy, w, da)
@@ -456,8 +493,10 @@ def cast_bf16(src, dst):
 
 
 def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, sf_out, cond_out, classes_out, xin_out,
-                apply_log, rowconst=None, rowconst_out=None):
+                apply_log, rowconst=None, rowconst_out=None, idx32_out=None):
     L.require_gpu(X, idx, x_out)
+    if idx32_out is not None:
+        assert idx32_out.dtype == torch.int32 and idx32_out.is_contiguous() and idx32_out.numel() >= idx.numel()
     G = X.shape[1]
     n = idx.numel()
     C = cond.shape[1] if cond is not None else 0
@@ -467,7 +506,8 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
                              ptr(x_out), ptr(goodloc_out), ptr(sf_out), ptr(cond_out), ptr(classes_out), ptr(xin_out),
                              dt_code(xin_out.dtype) if xin_out is not None else 0,
                              xin_out.stride(0) if xin_out is not None else 0, int(apply_log), ptr(rowconst),
-                             ptr(rowconst_out), stream()))
+                             ptr(rowconst_out), ptr(idx32_out), idx32_out.numel() if idx32_out is not None else 0,
+                             stream()))
 
 
 def combine_losses(losses4, weights, out6):

@@ -111,8 +111,11 @@ class _Loader:
     rng="device" draws on the GPU generator."""
 
     def __init__(self, dataset, batch_size, weights=None, num_samples=None, rng="reference", xin_dtype=None,
-                 apply_log=False, world=None, nb_const=False):
+                 apply_log=False, world=None, nb_const=False, resident_xin=None):
         self.nb_const = nb_const  # deliver the data-only NB term (sum goodloc*lgamma(x+1)) with every batch
+        # callable(batch rows) -> bool: leave the encoder input in the dataset's resident bf16 matrix (read in place by the
+        # row-indexed first-layer GEMMs) instead of writing a per-batch copy
+        self.resident_xin = resident_xin or (lambda n: False)
         self.ds, self.bs, self.weights, self.num_samples, self.rng = dataset, batch_size, weights, num_samples, rng
         self.xin_dtype, self.apply_log = xin_dtype, apply_log
         self.world = world  # data-parallel: batch_size is the GLOBAL batch, each rank gathers its own slice
@@ -151,7 +154,7 @@ class _Loader:
                     continue
                 sub = sub[self.world.rank * per:(self.world.rank + 1) * per]
             yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}),
-                                 self.nb_const, resident_rows=self.nb_const)
+                                 self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(sub.numel()))
 
 
 class Trainer:
@@ -237,18 +240,25 @@ class Trainer:
         if not log_in and xin_dtype == torch.float32:
             xin_dtype = None  # the encoder reads x itself
         nbc = self.model.recon_loss == "nb"
+        G, H0 = self.model.input_dim, self.model.hidden_layer_sizes[0]
+
+        def rx(n):  # both first-layer GEMMs (forward [n,H0] over G, weight gradient [H0,G] over n) on the 256x256 kernel
+            from . import ops
+            return (nbc and xin_dtype == torch.bfloat16 and n % 8 == 0
+                    and ops.gemm_tile(torch.bfloat16, n, H0, G) == 256 and ops.gemm_tile(torch.bfloat16, H0, G, n) == 256)
+
         if self.use_stratified_sampling:
             weights = torch.tensor(self.train_data.stratifier_weights)
             self.dataloader_train = _Loader(self.train_data, self.batch_size, weights, self.n_samples, self.rng,
-                                            xin_dtype, log_in, self.world, nbc)
+                                            xin_dtype, log_in, self.world, nbc, rx)
         else:
             self.dataloader_train = _Loader(self.train_data, self.batch_size, None, None, self.rng, xin_dtype, log_in,
-                                            self.world, nbc)
+                                            self.world, nbc, rx)
         if self.valid_data is not None:
             val_bs = min(self.batch_size, len(self.valid_data))
             self.val_iters_per_epoch = int(np.ceil(len(self.valid_data) / self.batch_size))
             self.dataloader_valid = _Loader(self.valid_data, val_bs, None, None, self.rng, xin_dtype, log_in, self.world,
-                                            nbc)
+                                            nbc, rx)
 
     def calc_alpha_coeff(self):
         """trainer.py:231-253."""

@@ -69,6 +69,22 @@ int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, in
                     int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
                     const float* alpha_dev, void* stream);
 
+/* Row-indexed forms of the gene-width forward and weight gradient (no counterpart in the reference, which gathers
+ * every batch on the host: trainers/celligner2/_utils.py:188-225): the batch is rows row_index[0..M) of a RESIDENT
+ * bf16 matrix A_full [a_rows, K] and is read where it lives by the LDS-DMA kernel (the per-lane source address carries
+ * the row), so no gathered copy of the encoder input is made.
+ *   c2_linear_fwd_rows:    Y[m][n]  = sum_k A_full[row_index[m]][k] W[n][k] (+ bias)
+ *   c2_linear_wgrad_rows:  dW[n][k] = alpha * sum_m dY[m][n] A_full[row_index[m]][k]
+ * bf16 operands only, shapes the 256x256 kernel takes (c2_gemm_tile(C2_BF16, ...) == 256), a_rows*lda < 2^31.
+ * row_index: int32, device; for the weight gradient it must be readable up to M rounded up to a multiple of 64
+ * (pad with any valid row).  Other shapes: error -- gather the rows (c2_gather_rows) and use the plain entry points. */
+int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_rows, const int32_t* row_index, const void* W,
+                       int64_t ldw, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
+                       int64_t slab_stride, const float* bias, void* stream);
+int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64_t lda, int64_t a_rows,
+                         const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
+                         int64_t slab_stride, const float* alpha_dev, void* stream);
+
 /* Block-tile edge (128 or 256) the three GEMM entry points above use for operand dtype `dtype` and an
  * [M,N] output reduced over R: callers size `nslab` from it so that a launch fills the 256 CUs.
  * 0 = this dtype cannot take the shape (C2_BF16X3P only).
@@ -218,12 +234,14 @@ int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * rows idx[0..n) of x/goodloc/sizefactor/cond/classes are gathered into dense batch tensors; xin
  * (= log(1+x) or x, dtype xin_dtype) is produced in the same pass (may be NULL).  x_out and goodloc_out may be
  * NULL when the consumer reads the resident rows itself (c2_recon_nb_fwd_bwd's row_index).  rowconst (may be NULL):
- * a second per-row fp32 scalar gathered like sizefactor (the dataset's c2_nb_row_const vector). */
+ * a second per-row fp32 scalar gathered like sizefactor (the dataset's c2_nb_row_const vector).  idx32_out (may be
+ * NULL): idx as int32 [idx32_len >= n], entries past n filled with the last index -- the row index of
+ * c2_linear_fwd_rows / c2_linear_wgrad_rows; with x_out, goodloc_out and xin_out all NULL nothing per gene is moved. */
 int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
                    const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n, float* x_out,
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
                    int xin_dtype, int64_t ldxin, int apply_log, const float* rowconst, float* rowconst_out,
-                   void* stream);
+                   int32_t* idx32_out, int64_t idx32_len, void* stream);
 
 /* ---- BatchNorm1d form of the layer tail (use_bn=True: modules.py:298-302, 405-413, 445-449, 557-566, 596-600;
  * nn.BatchNorm1d(affine=True), eps 1e-5, momentum 0.1).  The statistics run over the batch, so the tail is cut at

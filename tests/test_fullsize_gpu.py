@@ -67,6 +67,13 @@ def test_deterministic_and_resident_rows_equal_gathered_copies(world):
     assert torch.equal(v1, v3)
     for n in g1:
         assert torch.equal(g1[n], g3[n]), n
+    # the encoder input left in the dataset's resident bf16 matrix, read in place by the row-indexed first-layer GEMMs
+    rx = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=True, resident_xin=True)
+    assert "xin_full" in rx and "xin" not in rx and rx["row_index32"].dtype == torch.int32
+    v4, g4 = _step(m, dict(rx), eps)
+    assert torch.equal(v1, v4)
+    for n in g1:
+        assert torch.equal(g1[n], g4[n]), n
 
 
 def test_row_permutation_invariance(world):
