@@ -109,11 +109,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("C2_BENCH_BACKEND", "nccl") != "nccl":
+        local %= torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     comm = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" (= RCCL) is the product path; C2_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed with several
+        # ranks sharing one GPU (RCCL needs one device per rank)
+        backend = os.environ.get("C2_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from celligner2_amd.parallel import DataParallelStep
         comm = DataParallelStep()
 
@@ -157,9 +165,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def trace(msg):  # C2_BENCH_TRACE=1: stage markers on stderr (rehearsals of the multi-rank path)
+        if os.environ.get("C2_BENCH_TRACE"):
+            import faulthandler
+            faulthandler.dump_traceback_later(60, exit=True)  # re-armed at every marker: fires only on a stall
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    trace("model, dataset and trainer built")
+    for i in range(args.warmup):
         trainer.on_iteration(next(stream))
+        trace(f"warmup step {i} launched")
     sync()
+    trace("warmup done")
     ops.PROFILE_GEMM = []  # (flops, start_event, end_event) of every gene-width GEMM launch in the timed region
     prof_host = None
     if os.environ.get("C2_BENCH_CPROFILE"):  # developer aid: cProfile of the host launch path of the timed steps
@@ -167,8 +184,9 @@ def main():
         prof_host = cProfile.Profile()
         prof_host.enable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         trainer.on_iteration(next(stream))
+        trace(f"timed step {i} launched")
     t_host = time.perf_counter() - t0  # the launch path alone (the GPU queue drains in sync())
     if prof_host is not None:
         import pstats
@@ -177,25 +195,32 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+    trace("timed steps done")
     model._engine().check_status()
     # Second, untuned-pipeline timing of the same K steps: every data-only term is evaluated INSIDE the step, as the
     # reference's forward does (log(1+x) of the batch, lgamma(x+1) of the NB likelihood; the batch's counts and mask
     # copied by the gather) instead of once per resident dataset.  Reported beside the headline value.
-    ld = trainer.dataloader_train
-    ld.nb_const, ld.resident_xin = False, (lambda n: False)
-    stream2 = batches()
-    for _ in range(2):
-        trainer.on_iteration(next(stream2))
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.on_iteration(next(stream2))
-    sync()
-    dt_all_in_step = time.perf_counter() - t1
-    tmax = torch.tensor([dt, dt_all_in_step], device=device, dtype=torch.float64)
+    dt_all_in_step = float("nan")
+    if world == 1:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
+        ld = trainer.dataloader_train
+        ld.nb_const, ld.resident_xin = False, (lambda n: False)
+        stream2 = batches()
+        for _ in range(2):
+            trainer.on_iteration(next(stream2))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.on_iteration(next(stream2))
+        sync()
+        dt_all_in_step = time.perf_counter() - t1
+    trace("second timing done")
+    if os.environ.get("C2_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, dt_all_in_step = float(tmax[0].item()), float(tmax[1].item())
+    dt = float(tmax.item())
     last = [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
     assert all(np.isfinite(last)), f"non-finite losses {last}"
 
@@ -224,8 +249,8 @@ def main():
                        "dataset_resident_terms": "log(1+x) as bf16 and the per-row sum of lgamma(x+1) are evaluated once "
                                                  "per dataset (identical values); see all_terms_in_step for the step "
                                                  "that evaluates them per batch like the reference's forward"},
-            "all_terms_in_step": {"value": cells / dt_all_in_step, "unit": "cells/s",
-                                  "ms_per_step": 1e3 * dt_all_in_step / args.steps},
+            "all_terms_in_step": ({"value": cells / dt_all_in_step, "unit": "cells/s",
+                                   "ms_per_step": 1e3 * dt_all_in_step / args.steps} if world == 1 else None),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": "c2::wide::gemm_wide_kernel<*,*,8> (gene-width Linear fwd/dgrad/wgrad)",

@@ -28,6 +28,10 @@ class DataParallelStep:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # gloo (CPU tests, rehearsals with several ranks on one GPU): device tensors are exchanged through explicit host
+        # copies (gloo's own handling of device tensors was seen to stall after a few steps with ranks sharing a GPU).
+        # RCCL ("nccl") is stream-ordered and takes the asynchronous path.
+        self._host_backend = dist.get_backend(group) != "nccl"
         self._side = None
         self._pending = []
         self.defer_last = False  # set by the optimizer wiring: the last bucket's wait moves into FusedAdam.step
@@ -53,6 +57,8 @@ class DataParallelStep:
     # -- forward collectives
     def allgather_rows(self, feat, cond):
         """[B,D] fp32 / [B,C] int64 of every rank stacked in rank order (equal B on all ranks)."""
+        if self._host_backend and feat.is_cuda:
+            return self._host_gather(feat), self._host_gather(cond)
         B = feat.shape[0]
         feat_all = torch.empty((self.world_size * B,) + tuple(feat.shape[1:]), dtype=feat.dtype, device=feat.device)
         cond_all = torch.empty((self.world_size * B,) + tuple(cond.shape[1:]), dtype=cond.dtype, device=cond.device)
@@ -60,21 +66,40 @@ class DataParallelStep:
         dist.all_gather_into_tensor(cond_all, cond.contiguous(), group=self.group)
         return feat_all, cond_all
 
+    # gloo with device tensors: the exchange is made on host copies (blocking), explicitly
+    def _host_gather(self, t):
+        h = t.detach().contiguous().cpu()
+        out = torch.empty((self.world_size * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=self.group)
+        return out.to(t.device)
+
+    def _host_reduce(self, t):
+        h = t.detach().contiguous().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(h.to(t.device).view_as(t))
+        return t
+
     def allgather_stats(self, part):
         """[2,H] fp32 statistics partial of every rank stacked in rank order -> [world,2,H]."""
+        if self._host_backend and part.is_cuda:
+            return self._host_gather(part).view((self.world_size,) + tuple(part.shape))
         out = torch.empty((self.world_size * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype,
                           device=part.device)  # the flat "concatenate along dim 0" form every backend takes
         dist.all_gather_into_tensor(out, part.contiguous(), group=self.group)
         return out.view((self.world_size,) + tuple(part.shape))
 
     def allreduce_scalars(self, t):
+        if self._host_backend and t.is_cuda:
+            return self._host_reduce(t)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     # -- backward collectives
     def allreduce_bucket_async(self, flat):
         """SUM all-reduce of one gradient bucket on a side stream, ordered after the work already queued."""
-        if flat.is_cuda:
+        if flat.is_cuda and self._host_backend:
+            self._host_reduce(flat)
+        elif flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
             ev = torch.cuda.Event()

@@ -22,6 +22,8 @@ def main():
     from oracle import c2_oracle as orc
 
     use_bn = len(sys.argv) > 1 and sys.argv[1] == "bn"
+    global NSTEPS
+    NSTEPS = 6
     G, hidden, L, C, P, B = 256, [48, 24], 8, 3, 4, 64
     cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=hidden, latent_dim=L, n_conditions=C, n_predictors=P,
                   recon_loss="nb", use_mmd=True, beta=20.0, use_bn=use_bn)
@@ -49,11 +51,17 @@ def main():
         tensors of the bucket that is still being all-reduced in a second launch, after the wait."""
         opt = FusedAdam(list(m.parameters()), lr=1e-3, eps=0.01, weight_decay=0.04, grad_sync=sync)
         m._forced_noise = dict(eps=torch.tensor(eps[sl]).cuda(), masks={})
-        r, k, mm, ce = m(**{k_: torch.tensor(v[sl]).cuda() for k_, v in full.items()})
-        (r + 1e-3 * k + mm + ce).backward()
-        opt.step()
+        first = None
+        for step in range(NSTEPS):  # several steps back to back, nothing synchronised in between
+            opt.zero_grad()
+            r, k, mm, ce = m(**{k_: torch.tensor(v[sl]).cuda() for k_, v in full.items()})
+            (r + 1e-3 * k + mm + ce).backward()
+            if step == 0:  # losses / gradients of the first step are compared; parameters after the last
+                first = (torch.stack([r, k, mm, ce]).detach().clone(),
+                         {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            opt.step()
         torch.cuda.synchronize()
-        return np.array([r.item(), k.item(), mm.item(), ce.item()]), {n: p.grad.clone() for n, p in m.named_parameters()}
+        return first[0].cpu().numpy().astype(np.float64), first[1]
 
     ref_l = ref_g = ref_m = None
     if rank == 0:
