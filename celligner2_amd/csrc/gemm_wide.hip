@@ -462,6 +462,164 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 on planes, fused: ONE pass over the reduction in which every K-tile brings its four operand tiles
+// (A_hi, B_hi, A_lo, B_lo; 16 KB each) and is multiplied three times (hi*hi + hi*lo + lo*hi) from the same
+// fragments -- 64 KB staged per 48 MFMAs of a wave instead of 96 KB per 48 (three passes over a virtual reduction,
+// each with its own pair of tiles), and a third as many barrier / LDS-DMA round trips, which is what bounds the
+// narrow layers (one 128x128 block per CU, 24 K-tiles of 16 MFMAs each before).  128x128 tile, 4 waves (2 x 2), each
+// wave 64x64; two stages of four slots (128 KB): while K-tile T is multiplied, T+1 is in flight.
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int NW = 4, BX = 128, MI = 2, WN = 2;
+    constexpr int TILE_BYTES = BX * BK * 2;  // 16 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int wg;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tiles = tiles_m * tiles_n;
+    const int split = wg / tiles;
+    int tm, tn;
+    {
+        const int t = wg - split * tiles;
+        const int per = GROUP_M * tiles_n;
+        const int gid = t / per, first = gid * GROUP_M;
+        const int gsz = min(tiles_m - first, GROUP_M);
+        const int u = t - gid * per;
+        tm = first + u % gsz;
+        tn = u / gsz;
+    }
+    const int m0 = tm * BX, n0 = tn * BX;
+    const int rbeg = split * a.r_per_split;
+    const int rend = min(a.R, rbeg + a.r_per_split);
+    const int rlen = max(rend - rbeg, 0);
+    const int nfull = rlen / BK;
+    const int ktail = rlen - nfull * BK;
+    const int nt = nfull + (ktail ? 1 : 0);
+
+    const int64_t offA = A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0;
+    const int64_t offB = B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0;
+    const bf16_t* pAh = reinterpret_cast<const bf16_t*>(a.A) + offA;
+    const bf16_t* pBh = reinterpret_cast<const bf16_t*>(a.B) + offB;
+    const bf16_t* pAl = reinterpret_cast<const bf16_t*>(a.A_lo) + offA;
+    const bf16_t* pBl = reinterpret_cast<const bf16_t*>(a.B_lo) + offB;
+    int voa[4], vob[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        voa[j] = stage_offset<A_RC, BX>(j, a.lda, m0, a.M, wave, lane);
+        vob[j] = stage_offset<B_RC, BX>(j, a.ldb, n0, a.N, wave, lane);
+    }
+    const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
+    const int64_t stepB = B_RC ? BK : (int64_t)BK * a.ldb;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // stage s (0/1) = slots 4s .. 4s+3 = (A_hi, B_hi, A_lo, B_lo) of one K-tile
+    auto issue = [&](int t, int s) {
+        char* d = smem + 4 * s * TILE_BYTES;
+        if (t < nfull) {
+            stage_dma<0, 4>(pAh, voa, d, wave);
+            stage_dma<0, 4>(pBh, vob, d + TILE_BYTES, wave);
+            stage_dma<0, 4>(pAl, voa, d + 2 * TILE_BYTES, wave);
+            stage_dma<0, 4>(pBl, vob, d + 3 * TILE_BYTES, wave);
+        } else {  // the partial last tile: through registers, zero filled
+            stage_tail<A_RC, BX>(pAh, voa, d, wave, lane, ktail);
+            stage_tail<B_RC, BX>(pBh, vob, d + TILE_BYTES, wave, lane, ktail);
+            stage_tail<A_RC, BX>(pAl, voa, d + 2 * TILE_BYTES, wave, lane, ktail);
+            stage_tail<B_RC, BX>(pBl, vob, d + 3 * TILE_BYTES, wave, lane, ktail);
+        }
+        pAh += stepA; pAl += stepA; pBh += stepB; pBl += stepB;
+    };
+    if (nt > 0) issue(0, 0);
+    for (int T = 0; T < nt; ++T) {
+        // tile T (issued one iteration ago) has landed; every wave is past its reads of tile T-1's stage
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (T + 1 < nt) issue(T + 1, (T + 1) & 1);
+        const char* d = smem + 4 * (T & 1) * TILE_BYTES;
+        const char *tAh = d, *tBh = d + TILE_BYTES, *tAl = d + 2 * TILE_BYTES, *tBl = d + 3 * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = read_frag<B_RC, BX>(tBh, wn * 64 + j * 32, ks, lane);
+                bl[j] = read_frag<B_RC, BX>(tBl, wn * 64 + j * 32, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = read_frag<A_RC, BX>(tAh, wm * 64 + i * 32, ks, lane);
+                al[i] = read_frag<A_RC, BX>(tAl, wm * 64 + i * 32, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue (as gemm_wide_kernel): accumulators transposed through LDS for 16-byte-per-lane stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
+    float* C = a.C + (int64_t)split * a.slab_stride;
+    float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+    const int col4 = n0 + wn * 64 + (lane & 15) * 4;
+    const bool vec_ok = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (col4 + 4 <= a.N);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (col4 + c < a.N) bv[c] = a.bias[col4 + c];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                wl[r * 64 + j * 32 + (lane & 31)] = acc[ii][j][e];
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = rr * 4 + (lane >> 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
+        const int row = m0 + wm * 64 + r;
+        if (row < a.M) {
+            float* dst = C + (int64_t)row * a.ldc + col4;
+            if (vec_ok) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = alpha * v[c] + bv[c];
+                *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (col4 + c < a.N) dst[c] = alpha * v[c] + bv[c];
+            }
+        }
+    }
+}
+
 }  // namespace wide
 
 #if C2_GEMM_DBG & 16
@@ -525,8 +683,31 @@ int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t 
     return 0;
 }
 
+static void launch_x3(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+    using namespace wide;
+    constexpr int BX = 128;
+    constexpr int LDS = 8 * BX * BK * 2;  // two stages of four 16 KB slots
+    const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;
+    const dim3 grid(tiles_m * tiles_n * nslab);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    if (layout == 0)
+        hipLaunchKernelGGL((gemm_x3_kernel<true, true>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+    else if (layout == 1)
+        hipLaunchKernelGGL((gemm_x3_kernel<true, false>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_x3_kernel<false, false>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+}
+
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {
+    static const bool x3_passes = getenv("C2_X3_PASSES") != nullptr;  // A/B: the three-pass instance
     if (tile == 256) launch_nw<8>(layout, a, nslab, stream);
+    else if (a.A_lo && !x3_passes) launch_x3(layout, a, nslab, stream);
     else launch_nw<4>(layout, a, nslab, stream);
     return 0;
 }
