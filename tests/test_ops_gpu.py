@@ -699,3 +699,38 @@ def test_linear_rows_equal_gathered_operands(M, N, K, nslab):
     assert torch.equal(d0, d1)
     with pytest.raises(ops.L.C2Error):  # a shape the 256x256 kernel does not take: the caller gathers instead
         ops.linear_fwd_rows(a_full[:, :64], rows_p, 64, w[:128, :64].contiguous(), torch.empty(64, 128, device=DEV))
+
+
+def test_mmd_at_the_eight_gpu_shape():
+    """One rank's share of the 8-GPU weak-scaling step: 4096 own rows against 32 768 gathered rows, D = 64.
+    Too large for the oracle: the partition (rows beyond the 8192 whose keys stay in registers) is checked against
+    numpy's unique rows, and the four-wave fast MMD kernel against the general one-wave kernel (taken for a feature
+    matrix whose row stride is not a multiple of 4), which the small cases pin to the oracle."""
+    ops = _ops()
+    Bg, Bl, D, C, row0 = 32768, 4096, 64, 3, 8192
+    g = torch.Generator(device="cpu").manual_seed(5)
+    f = torch.randn(Bg, D, generator=g).to(DEV)
+    lab = torch.randint(0, C, (Bg,), generator=g)
+    cond = torch.zeros(Bg, C, dtype=torch.int64)
+    cond[torch.arange(Bg), lab] = 1
+    part_id = torch.empty(Bg, device=DEV, dtype=torch.int32)
+    wt = torch.empty(64 * 64, device=DEV)
+    ws_p = torch.empty(int(ops.lib.c2_partition_ws(Bg)), device=DEV, dtype=torch.uint8)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.partition(cond.to(DEV), C, None, None, part_id, wt, ws_p, status)
+    assert status.item() == 0
+    parts = orc.partition_index(cond.numpy(), None)
+    pid = part_id.cpu().numpy()
+    for k, idx in enumerate(parts):
+        assert (pid[idx] == k).all()
+    out = []
+    for ld in (D, D + 1):  # row stride 64: fast kernel; 65: general kernel
+        buf = torch.zeros(Bg, ld, device=DEV)
+        buf[:, :D] = f
+        feat = buf[:, :D]
+        loss = torch.zeros(1, device=DEV)
+        df = torch.empty(Bl, D, device=DEV)
+        ops.mmd(feat, part_id, wt, row0, Bl, 3.0, loss, df, torch.empty(ops.mmd_ws(Bl, Bg, D), device=DEV))
+        out.append((loss.item(), df))
+    assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[1][0]), (out[0][0], out[1][0])
+    assert rel(out[0][1], out[1][1].cpu().numpy()) < 1e-4
