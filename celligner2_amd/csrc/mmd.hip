@@ -36,8 +36,8 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
     for (int i = tid; i < MAXP; i += 1024) s_cnt[i] = 0;
     __syncthreads();
     // keys: column 0 is the most significant bit -> numeric order == lexicographic row order
-    // (the first KREG keys of a thread also stay in registers: batches up to 8192 rows never re-read global memory)
-    constexpr int KREG = 8;
+    // (the first KREG keys of a thread also stay in registers: batches up to 32 768 rows never re-read global memory)
+    constexpr int KREG = 32;
     unsigned long long kreg[KREG];
     int bad = 0;
 #pragma unroll
