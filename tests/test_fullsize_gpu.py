@@ -79,7 +79,7 @@ def test_deterministic_and_resident_rows_equal_gathered_copies(world):
 def test_row_permutation_invariance(world):
     data, models, idx, eps = world
     m = models["bf16"]
-    perm = torch.randperm(B, device=DEV)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
     v1, g1 = _step(m, dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True)), eps)
     v2, g2 = _step(m, dict(data.gather(idx[perm], torch.bfloat16, True, nb_const=True, resident_rows=True)), eps[perm])
     assert torch.allclose(v1, v2, rtol=2e-5, atol=1e-6), (v1, v2)
