@@ -391,6 +391,19 @@ __global__ __launch_bounds__(64, FAST ? 3 : 1) void mmd_tile_kernel(const TF* __
 #ifndef C2_MMD_SKIP_T
 #define C2_MMD_SKIP_T 160.f  // 2^-160 is below the smallest fp32 denormal: the term is exactly 0
 #endif
+// C2_MMD_SPLIT_GRAM (default 1): the Gram block on the bf16 matrix pipe with both operands split three ways
+// (x = hi + mid + lo, 8 significant bits each; products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid: the dropped ones
+// are below 2^-23 of |x||y|, the rounding of an fp32 product): 24 v_mfma_f32_32x32x16_bf16 (32 cycles each) per tile
+// instead of 32 v_mfma_f32_32x32x2_f32 (64 cycles each).  0: the fp32-MFMA form.
+#ifndef C2_MMD_SPLIT_GRAM
+#define C2_MMD_SPLIT_GRAM 1
+#endif
+__device__ __forceinline__ void split3(float x, bf16_t& h, bf16_t& m, bf16_t& l) {
+    h = f2bf(x);
+    const float r1 = x - bf2f(h);
+    m = f2bf(r1);
+    l = f2bf(r1 - bf2f(m));
+}
 constexpr int FW = 4;  // waves (row tiles) per block
 #ifdef C2_MMD_DBG
 __device__ unsigned long long g_mmd_clk[8];
@@ -406,6 +419,11 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
                                                               float* __restrict__ loss_partials,
                                                               float* __restrict__ gslabs /*[jsplit][Bl][D]*/) {
     __shared__ float ldsJ[2][TS * LDT];
+#if C2_MMD_SPLIT_GRAM
+    // the column tile again as three bf16 planes [32 rows][8 chunks of 8 features], chunk c of row r at c ^ (r & 7)
+    // (the fragment read -- 16 B per lane, rows down the lanes -- is then bank-conflict free)
+    __shared__ __attribute__((aligned(16))) bf16_t ldsP[2][3][TS * 64];
+#endif
     __shared__ float ldsW[FW][TS * (TS + 1)];
     __shared__ float ldsNi[FW][TS];
     __shared__ int ldsPi[FW][TS];
@@ -419,6 +437,29 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
     const int64_t i0 = (int64_t)it * TS;
     const bool active = it < nit;  // wave-uniform; an inactive wave still stages tiles and joins the barriers
 
+#if C2_MMD_SPLIT_GRAM
+    // Gram A operand of this wave's rows, split: k-step ks, lane (lo, hi) holds f[i0 + lo][16 ks + 8 hi + 0..7]
+    bf16x8 afh[4], afm[4], afl[4];
+    {
+        const bool ok = active && i0 + lo < Bl;
+        const float* fr = f + (row0 + i0 + lo) * ldf;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s16x8 h8, m8, l8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * ks + 8 * hi + e;
+                const float x = (ok && d < D) ? fr[d] : 0.f;
+                bf16_t h, m, l;
+                split3(x, h, m, l);
+                h8[e] = (short)h; m8[e] = (short)m; l8[e] = (short)l;
+            }
+            afh[ks] = __builtin_bit_cast(bf16x8, h8);
+            afm[ks] = __builtin_bit_cast(bf16x8, m8);
+            afl[ks] = __builtin_bit_cast(bf16x8, l8);
+        }
+    }
+#else
     // Gram A operand of this wave's rows: step s, lane (lo, hi) holds f[i0 + lo][2 s + hi]
     float afr[DC / 2];
     {
@@ -430,6 +471,7 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
             afr[s2] = (ok && d < D) ? fr[d] : 0.f;
         }
     }
+#endif
     // row norms / partitions of the wave's 32 rows live in LDS (read back per pair: registers are the scarce resource)
     const int64_t gi0 = row0 + i0 + 4 * hi;
     if (lane < TS) {
@@ -474,6 +516,19 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
             const int r = idx >> 4, c4 = (idx & 15) * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[r * LDT + c4 + q] = vn[k][q];
+#if C2_MMD_SPLIT_GRAM
+            bf16_t h[4], m[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split3(vn[k][q], h[q], m[q], l[q]);
+            const int off = r * 64 + (((c4 >> 3) ^ (r & 7)) << 3) + (c4 & 7);  // elements; 8-byte aligned
+            u32x2 ph, pm, pl;
+            ph[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); ph[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+            pm[0] = (unsigned)m[0] | ((unsigned)m[1] << 16); pm[1] = (unsigned)m[2] | ((unsigned)m[3] << 16);
+            pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+            *reinterpret_cast<u32x2*>(&ldsP[buf][0][off]) = ph;
+            *reinterpret_cast<u32x2*>(&ldsP[buf][1][off]) = pm;
+            *reinterpret_cast<u32x2*>(&ldsP[buf][2][off]) = pl;
+#endif
         }
     };
     const int64_t njt = (Bg + TS - 1) / TS;
@@ -494,6 +549,30 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
         MMD_T(0)
         if (jt + 1 < jt_end) tile_load((jt + 1) * TS);
         if (!active) continue;
+#if C2_MMD_SPLIT_GRAM
+        // ---- Gram block on three-way split bf16 operands (fp32-product accuracy: the distance is a cancellation)
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (16 * ks < D) {
+                const int off = lo * 64 + (((2 * ks + hi) ^ (lo & 7)) << 3);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ldsP[buf][0][off]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(&ldsP[buf][1][off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&ldsP[buf][2][off]);
+                // small terms first; two chains
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afm[ks], bm, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[ks], bl, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[ks], bh, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[ks], bm, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afm[ks], bh, acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[ks], bh, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
+#else
         // ---- Gram block (fp32 MFMA: the distance is a cancellation)
         // two independent accumulation chains: a dependent MFMA waits out the previous one's 16 passes (and whatever
         // the SIMD's other wave slipped in between), two chains issue back to back
@@ -510,6 +589,7 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
+#endif
         const int64_t gj = j0 + lo;
         const bool jok = gj < Bg;
         const float nj = ldsNj[buf][lo];
