@@ -7,7 +7,6 @@ the device and are averaged once per epoch (log_sync="epoch") instead of six .it
 """
 from __future__ import annotations
 
-import os
 import sys
 import time
 from collections import defaultdict
