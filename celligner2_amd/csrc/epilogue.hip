@@ -261,7 +261,15 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
         const int c = (lane + 64 * i) * 4;
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         if (c < H) {
-            for (int s = 0; s < nslab; ++s) h += *reinterpret_cast<const f32x4*>(Y + s * slab_stride + row * ldy + c);
+            // the slabs in groups of four independent loads (a run-time trip count would serialise load and add)
+            for (int s0 = 0; s0 < nslab; s0 += 4) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    t[u] = (s0 + u < nslab) ? *reinterpret_cast<const f32x4*>(Y + (s0 + u) * slab_stride + row * ldy + c)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                h += (t[0] + t[1]) + (t[2] + t[3]);
+            }
             if (bias) h += *reinterpret_cast<const f32x4*>(bias + c);
             if (crow) {
                 for (int j = 0; j < C; ++j) {
@@ -335,7 +343,14 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
         const int c = (lane + 64 * i) * 4;
         f32x4 d = {0.f, 0.f, 0.f, 0.f}, yh = d;
         if (c < H) {
-            for (int s = 0; s < nslab; ++s) d += *reinterpret_cast<const f32x4*>(dA + s * slab_stride + row * ldda + c);
+            for (int s0 = 0; s0 < nslab; s0 += 4) {  // groups of four independent loads
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    t[u] = (s0 + u < nslab) ? *reinterpret_cast<const f32x4*>(dA + (s0 + u) * slab_stride + row * ldda + c)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                d += (t[0] + t[1]) + (t[2] + t[3]);
+            }
             if (extra) d += es * *reinterpret_cast<const f32x4*>(extra + row * ldextra + c);
             if (mask) {
                 const unsigned mb = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + c);
