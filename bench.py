@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the Celligner2 training step (forward + backward + Adam) on MI355X.
 
-python bench.py --gpus N --steps K --warmup W      (N>1: launched under torch.distributed.run, one rank per GPU)
+python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set, as the driver launches it) this process
+is one of the N ranks; started plainly (`python bench.py --gpus N`) it starts the N ranks itself, as a child
+`python -m torch.distributed.run` BEFORE anything touches the GPU, and exits with the child's code.  It never times fewer
+GPUs than asked for: a world size that differs from --gpus, or fewer devices than ranks, is an error (exit 2).
 
 Workload (BASELINE.json configs[3], SURVEY.md 8(d) "C4"): synthetic 100k x 19k expression matrix resident in
 HBM, hidden [1024,512], latent 64, 3 conditions, NB reconstruction, multi-dataset MMD on z, LayerNorm,
@@ -24,6 +29,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+PMC_JSON = "r02_gemm_pmc.json"  # HBM traffic of the gene-width GEMM launches (tools/pmc_step_json.py)
 
 CONFIGS = {
     # name: G, hidden, latent, C, P, cls_hidden, per-GPU batch, N rows, beta
@@ -60,8 +67,19 @@ def synth_dataset(cfg, device, seed=2020):
     return DeviceDataset.from_tensors(X, X.sum(1), good, cond, pred, minweight=0.2)
 
 
-def cpu_baseline(cfg, seconds=20.0):
-    """The numpy oracle's full step (forward + backward + Adam) on a bounded sample of the workload."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, seconds=25.0, warm=3, timed=20):
+    """The numpy oracle's full step (forward + backward + Adam) on a bounded sample of the workload: `warm` warm-up
+    steps, then up to `timed` steps (fewer when the time bound is reached), median step time."""
     from oracle import c2_oracle as orc
     Bc = 256
     ocfg = orc.Cfg(input_dim=cfg["G"], hidden_layer_sizes=cfg["hidden"], latent_dim=cfg["latent"],
@@ -80,18 +98,33 @@ def cpu_baseline(cfg, seconds=20.0):
     state = {}
     times = []
     t_end = time.time() + seconds
-    n = 0
-    while n < 2 or (time.time() < t_end and n < 50):
+    while len(times) < warm + 2 or (time.time() < t_end and len(times) < warm + timed):
         eps = rng.standard_normal((Bc, cfg["latent"])).astype(np.float32)
         t0 = time.time()
         out = orc.forward_backward(params, ocfg, batch, eps, gscale=(1, 1e-3, 1, 1))
         orc.adam_step(params, out["grads"], state)
         times.append(time.time() - t0)
-        n += 1
-    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    kept = times[warm:]
+    med = float(np.median(kept))
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return dict(value=Bc / med, unit="cells/s", cores=cores, kind="port",
-                sample=f"{len(times)} steps of {Bc} cells, same model/genes (numpy fp32 oracle, BLAS threads={cores})")
+    return dict(value=Bc / med, unit="cells/s", cores=cores, kind="port", cpu=_cpu_model(),
+                sample=f"{warm} warm-up + {len(kept)} timed steps of {Bc} cells (median), same model/genes "
+                       f"(numpy fp32 oracle, BLAS threads={cores})")
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run.  Nothing here
+    has touched the GPU yet (device_count() does not initialise it), and the child is a fresh process tree."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -103,25 +136,44 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="cells per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1, help="1/0: replay the step as a HIP graph (default: the config's)")
+    ap.add_argument("--steady-seconds", type=float, default=1.2, help="length of the second, longer timing loop")
     args = ap.parse_args()
 
+    backend = os.environ.get("C2_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(_self_launch(args.gpus))
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            sys.exit(2)
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        print(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {ndev} "
+              "(C2_BENCH_BACKEND=gloo rehearses the N-rank code path with ranks sharing a GPU)", file=sys.stderr)
+        sys.exit(2)
+
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("C2_BENCH_BACKEND", "nccl") != "nccl":
-        local %= torch.cuda.device_count()  # rehearsal: ranks share the GPUs there are
+    if backend != "nccl":
+        local %= max(ndev, 1)  # rehearsal: ranks share the GPUs there are
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     comm = None
     if world > 1:
         # "nccl" (= RCCL) is the product path; C2_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed with several
         # ranks sharing one GPU (RCCL needs one device per rank)
-        backend = os.environ.get("C2_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
         from celligner2_amd.parallel import DataParallelStep
         comm = DataParallelStep()
 
@@ -133,22 +185,25 @@ def main():
     if args.batch:
         cfg["B"] = args.batch
     B = cfg["B"]
+    Bglob = B * world
+    # every batch of an epoch is a full global batch: the loader keeps a short last batch (as the reference's does), which
+    # would put a first-seen shape -- and its buffer allocation -- inside the timed region
+    n_samples = (cfg["N"] // Bglob) * Bglob
+    if n_samples == 0:
+        print(f"bench.py: global batch {Bglob} exceeds the dataset ({cfg['N']} rows)", file=sys.stderr)
+        sys.exit(2)
     torch.manual_seed(2020)
     model = Celligner2(cfg["G"], cfg["hidden"], cfg["latent"], 0.05, False, "nb", conditions=[f"c{i}" for i in range(cfg["C"])],
                        use_mmd=True, mmd_on="z", beta=cfg["beta"], predictors=[f"p{i}" for i in range(cfg["P"])],
                        classifier_hidden_layer_sizes=cfg["cls_hidden"], precision=args.precision)
     data = synth_dataset(cfg, device)
-    trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=B * world, use_leiden=False,
+    use_graph = bool(cfg.get("graph", False)) if args.graph < 0 else bool(args.graph)
+    trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=Bglob, use_leiden=False,
                                 alpha_kl=1e-3, monitor=False, use_early_stopping=False, rng="device", world=comm,
-                                seed=2020)
+                                seed=2020, n_samples=n_samples, **({"graph": True} if use_graph else {}))
     trainer.initialize_loaders()
     model.train()
-    names = {id(p): n for n, p in model.named_parameters()}
-    from celligner2_amd.optim import FusedAdam
-    lookup, updated = model._adam_hooks()
-    trainer.optimizer = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=0.01,
-                                  weight_decay=0.04, shadow_lookup=lookup, on_updated=updated,
-                                  grad_sync=getattr(trainer, "world", None))
+    trainer.optimizer = trainer.make_optimizer(lr=1e-3, eps=0.01)
     trainer.epoch, trainer.iter = 0, 0
     from collections import defaultdict
     trainer.iter_logs = defaultdict(list)
@@ -159,6 +214,12 @@ def main():
                 yield b
 
     stream = batches()
+    rows_done = [0]
+
+    def step(src):
+        b = next(src)
+        rows_done[0] += int(b["sizefactor"].numel())  # rows this rank really processed (host-side shape, no sync)
+        trainer.on_iteration(b)
 
     def sync():
         if world > 1:
@@ -171,9 +232,31 @@ def main():
             faulthandler.dump_traceback_later(60, exit=True)  # re-armed at every marker: fires only on a stall
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
+    def timed(n, src, host=False):
+        """n steps between two (barrier + device sync) points: (seconds, rows of this rank, host launch seconds)."""
+        sync()
+        rows_done[0] = 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(src)
+            trace(f"timed step {i} launched")
+        t_host = time.perf_counter() - t0  # the launch path alone (the GPU queue drains in sync())
+        sync()
+        return time.perf_counter() - t0, rows_done[0], t_host
+
+    def over_ranks(dt, rows):
+        """MAX of the time, SUM of the rows over ranks."""
+        if world == 1:
+            return dt, rows
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        r = torch.tensor([rows], device=device, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return float(t.item()), int(r.item())
+
     trace("model, dataset and trainer built")
     for i in range(args.warmup):
-        trainer.on_iteration(next(stream))
+        step(stream)
         trace(f"warmup step {i} launched")
     sync()
     trace("warmup done")
@@ -183,79 +266,83 @@ def main():
         import cProfile
         prof_host = cProfile.Profile()
         prof_host.enable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        trainer.on_iteration(next(stream))
-        trace(f"timed step {i} launched")
-    t_host = time.perf_counter() - t0  # the launch path alone (the GPU queue drains in sync())
+    dt, rows, t_host = timed(args.steps, stream)
     if prof_host is not None:
         import pstats
         prof_host.disable()
         pstats.Stats(prof_host, stream=sys.stderr).sort_stats("tottime").print_stats(35)
-    sync()
-    dt = time.perf_counter() - t0
     prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
     trace("timed steps done")
     model._engine().check_status()
-    # Second, untuned-pipeline timing of the same K steps: every data-only term is evaluated INSIDE the step, as the
+    dt, cells = over_ranks(dt, rows)
+    # The same pipeline over a longer loop (>= --steady-seconds): the K-step region above lasts tens of milliseconds,
+    # too short for a power-managed chip to settle; `value` stays the K-step figure the contract asks for.
+    n_steady = max(args.steps, int(np.ceil(args.steady_seconds / max(dt / args.steps, 1e-6))))
+    if world > 1:  # every rank must run the same number of steps
+        ns = torch.tensor([n_steady], device=device, dtype=torch.int64)
+        dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+        n_steady = int(ns.item())
+    dt_ss, rows_ss, _ = timed(n_steady, stream)
+    dt_ss, cells_ss = over_ranks(dt_ss, rows_ss)
+    trace("steady-state loop done")
+    # Third, untuned-pipeline timing of the same K steps: every data-only term is evaluated INSIDE the step, as the
     # reference's forward does (log(1+x) of the batch, lgamma(x+1) of the NB likelihood; the batch's counts and mask
     # copied by the gather) instead of once per resident dataset.  Reported beside the headline value.
-    dt_all_in_step = float("nan")
+    all_in_step = None
     if world == 1:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
         ld = trainer.dataloader_train
         ld.nb_const, ld.resident_xin = False, (lambda n: False)
+        if hasattr(trainer, "drop_graph"):
+            trainer.drop_graph()
         stream2 = batches()
         for _ in range(2):
-            trainer.on_iteration(next(stream2))
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.on_iteration(next(stream2))
-        sync()
-        dt_all_in_step = time.perf_counter() - t1
+            step(stream2)
+        dt2, rows2, _ = timed(args.steps, stream2)
+        all_in_step = {"value": rows2 / dt2, "unit": "cells/s", "ms_per_step": 1e3 * dt2 / args.steps}
     trace("second timing done")
     if os.environ.get("C2_BENCH_TRACE"):
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
     last = [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
     assert all(np.isfinite(last)), f"non-finite losses {last}"
+    n_gpus = dist.get_world_size() if world > 1 else 1
 
     if rank == 0:
-        cells = B * world * args.steps
         gemm_ms = sum(s.elapsed_time(e) for _, s, e in prof)
         gemm_flops = sum(f for f, _, _ in prof)
         n_launch = max(len(prof), 1)
         peak = 2500.0 if args.precision == "bf16" else 157.3
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM bytes per GEMM launch: measured in separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-        # profiles/r01_gemm_pmc.json); only valid for the configuration it was measured on
+        # profiles/*_gemm_pmc.json); only valid for the configuration it was measured on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", PMC_JSON)
         if args.config == "c4" and args.precision == "bf16" and B == CONFIGS["c4"]["B"] and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+        H1 = cfg["hidden"][0]
         out = {
             "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes",
-            "value": cells / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": cells / dt, "unit": "cells/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "host_ms_per_step": 1e3 * t_host / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {cfg['desc']}; {B} cells/GPU/step, global batch {B * world}, "
+            "cells_timed": cells,
+            "config": {"workload": f"{args.config}: {cfg['desc']}; {B} cells/GPU/step, global batch {Bglob}, "
                                    f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
-                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "global_batch": Bglob, "parallelism": f"dp{n_gpus}", "backend": backend if world > 1 else None,
+                       "epoch_rows": n_samples, "hip_graph": use_graph,
                        "dataset_resident_terms": "log(1+x) as bf16 and the per-row sum of lgamma(x+1) are evaluated once "
                                                  "per dataset (identical values); see all_terms_in_step for the step "
                                                  "that evaluates them per batch like the reference's forward"},
-            "all_terms_in_step": ({"value": cells / dt_all_in_step, "unit": "cells/s",
-                                   "ms_per_step": 1e3 * dt_all_in_step / args.steps} if world == 1 else None),
+            "steady_state": {"value": cells_ss / dt_ss, "unit": "cells/s", "steps": n_steady,
+                             "ms_per_step": 1e3 * dt_ss / n_steady, "seconds": dt_ss},
+            "all_terms_in_step": all_in_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": "c2::wide::gemm_wide_kernel<*,*,8> (gene-width Linear fwd/dgrad/wgrad)",
                          "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
-                         "gemm_ms_per_step": gemm_ms / args.steps},
+                         "gemm_ms_per_step": gemm_ms / args.steps, "gemm_flops_per_step": gemm_flops / args.steps,
+                         "gemm_flops_per_step_expected": 5 * 2.0 * B * cfg["G"] * H1},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -102,11 +102,11 @@ extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, doub
     h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);  // as torch: 1-beta in double
     h.eps = (float)eps; h.wd = (float)weight_decay; h.clip = (float)clip_value;
     h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    for (int s = 0; s < n_tensors; s += kMaxT) {
+    for (int i = 0; i < n_tensors;) {  // one launch per kMaxT NON-EMPTY descriptors; i = descriptors consumed so far
         AdamTable tab;
         tab.n = 0;
         int blocks = 0;
-        for (int i = s; i < n_tensors && tab.n < kMaxT; ++i) {
+        for (; i < n_tensors && tab.n < kMaxT; ++i) {
             const c2_adam_tensor& d = desc_host[i];
             if (d.n == 0) continue;
             C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");

@@ -555,10 +555,17 @@ class StepEngine:
         inv_B = 1.0 / Bn
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
         self._aplanes = {}
-        ls = self.buf("losses+status", (8,))  # one zero-fill: 4 fp32 losses, 2 int32 status words
-        ls.zero_()
-        losses = self._ws["losses"] = ls[0:4]
-        status = self._ws["status"] = ls[4:6].view(torch.int32)
+        losses = self._ws["losses"] = self.buf("losses4", (4,))
+        losses.zero_()
+        # status words are STICKY: the kernels only ever write them on an error, and check_status() alone clears them,
+        # so a bad batch anywhere in an epoch is still reported at the epoch's end
+        status = self._ws.get("status")
+        if status is None:
+            status = self._ws["status"] = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        # every forward that saves activations for a backward gets a generation number; backward(gen=...) refuses a
+        # stale one (two forwards before one backward would silently differentiate the second)
+        if save:
+            self.generation = getattr(self, "generation", 0) + 1
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
         pre = batch.get("xin")  # already produced by the device-resident gather
@@ -676,9 +683,17 @@ class StepEngine:
         return losses
 
     # ------------------------------------------------------------------ backward
-    def backward(self, g):
+    def backward(self, g, gen=None):
         """g: fp32 device tensor [4] = upstream gradients of (recon, kl, mmd, class_ce).
-        Fills self.grad[name] for every parameter with requires_grad and returns that dict."""
+        Fills self.grad[name] for every parameter with requires_grad and returns that dict.
+        gen: the generation number of the forward this backward belongs to (checked when given)."""
+        if gen is not None and gen != getattr(self, "generation", None):
+            raise RuntimeError(
+                "backward of a forward whose saved activations have been overwritten: the engine keeps ONE workspace per "
+                "model, so each training forward must be followed by its backward before the next training forward "
+                "(sum the losses of one forward, or accumulate gradients over separate forward/backward pairs)")
+        if self.comm is not None:
+            self.comm.wait_deferred()  # a bucket of the previous backward still being reduced (no optimizer step since)
         cfg = self.cfg
         B, cond, masks = self._B, self._cond, self._masks
         self._touched = set()  # parameters outside this step's graph get no gradient (torch leaves .grad None)
@@ -854,6 +869,8 @@ class StepEngine:
         if st is None:
             return
         s = st.tolist()
+        if s[0] or s[1]:
+            st.zero_()
         if s[0]:
             raise IndexError("condition values outside {0,1} reached the NB dispersion one-hot "
                              "(the reference's scatter_ raises 'index out of range' here)")

@@ -121,6 +121,36 @@ class Classifier(nn.Module):  # modules.py:516-633
 
 
 # ------------------------------------------------------------------ autograd bridge
+def _keep_accumulated(model, eng):
+    """Before the engine's backward rewrites its gradient arena: a parameter whose .grad still IS an arena view handed
+    over by an earlier backward (gradient accumulation, zero_grad(set_to_none=False)) gets a private copy, so that the
+    accumulated value survives and autograd adds this step's gradient to it."""
+    flat = getattr(eng, "grad_flat", None)
+    if flat is None:
+        return
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    for p in model._param_list:
+        if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+            p.grad = p.grad.clone()
+
+
+def _hand_over(model, eng, grads):
+    """Per-parameter return values of the autograd node's backward.  When no parameter holds a gradient yet
+    (zero_grad(set_to_none=True), the default) the engine's persistent arena views BECOME p.grad -- no copy, and the
+    optimizer may overlap the last bucket's all-reduce.  Otherwise autograd must accumulate, so copies are returned:
+    they are taken only after every bucket's exchange has landed (a clone of a bucket still in flight would read
+    un-reduced values, and the optimizer could not know to wait for it)."""
+    names, params = model._param_names, model._param_list
+    if all(p.grad is None for p in params):
+        for n, p in zip(names, params):
+            if p.requires_grad and n in grads:
+                p.grad = grads[n]
+        return tuple(None for _ in params)
+    if eng.comm is not None:
+        eng.comm.wait_deferred()
+    return tuple((grads[n].clone() if (p.requires_grad and n in grads) else None) for n, p in zip(names, params))
+
+
 class _StepFn(torch.autograd.Function):
     """The four losses as one autograd node: forward and the unit-upstream loss gradients are computed by the
     engine in the forward pass, `backward` runs the engine's backward chain with the incoming (device) scalars."""
@@ -129,7 +159,7 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, model, batch, eps, masks, *params):
         eng = model.__dict__["_eng"]  # validated by Celligner2.forward just before
         losses = eng.forward(batch, eps, masks, train=model.training, save=True)
-        ctx.model = model
+        ctx.model, ctx.gen = model, eng.generation
         out = losses.clone()
         return out[0], out[1], out[2], out[3]
 
@@ -138,17 +168,9 @@ class _StepFn(torch.autograd.Function):
         model = ctx.model
         eng = model.__dict__["_eng"]
         g = torch.stack([gi if gi is not None else torch.zeros((), device=eng.dev) for gi in (g0, g1, g2, g3)]).float()
-        grads = eng.backward(g)
-        names = model._param_names
-        params = model._param_list
-        if all(p.grad is None for p in params):
-            # hand the engine's persistent gradient buffers over without a copy
-            for n, p in zip(names, params):
-                if p.requires_grad and n in grads:
-                    p.grad = grads[n]
-            return (None, None, None, None) + tuple(None for _ in params)
-        return (None, None, None, None) + tuple(
-            (grads[n].clone() if (p.requires_grad and n in grads) else None) for n, p in zip(names, params))
+        _keep_accumulated(model, eng)
+        grads = eng.backward(g, gen=ctx.gen)
+        return (None, None, None, None) + _hand_over(model, eng, grads)
 
 
 class _StepTotalFn(torch.autograd.Function):
@@ -162,7 +184,7 @@ class _StepTotalFn(torch.autograd.Function):
         losses = eng.forward(batch, eps, masks, train=model.training, save=True)
         out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
         ops.combine_losses(losses, weights, out6)
-        ctx.model, ctx.weights = model, weights
+        ctx.model, ctx.weights, ctx.gen = model, weights, eng.generation
         ctx.set_materialize_grads(False)  # no zero-fill launch for the loss vector's (absent) gradient
         total = out6[4]
         ctx.mark_non_differentiable(out6)
@@ -173,16 +195,9 @@ class _StepTotalFn(torch.autograd.Function):
         model = ctx.model
         eng = model.__dict__["_eng"]
         g = ops.scale4(gtotal.float().contiguous() if gtotal is not None else None, ctx.weights, eng.buf("gseed", (4,)))
-        grads = eng.backward(g)
-        names, params = model._param_names, model._param_list
-        head = (None, None, None, None, None)
-        if all(p.grad is None for p in params):
-            for n, p in zip(names, params):
-                if p.requires_grad and n in grads:
-                    p.grad = grads[n]
-            return head + tuple(None for _ in params)
-        return head + tuple((grads[n].clone() if (p.requires_grad and n in grads) else None)
-                            for n, p in zip(names, params))
+        _keep_accumulated(model, eng)
+        grads = eng.backward(g, gen=ctx.gen)
+        return (None, None, None, None, None) + _hand_over(model, eng, grads)
 
 
 class Celligner2(nn.Module):
@@ -376,22 +391,31 @@ class Celligner2(nn.Module):
             cls_shapes = [(f"cls.D{i}", (B, h)) for i, h in enumerate(self.classifier_hidden_layer_sizes)]
         training = self.training
         masks = {}
+        # Data-parallel runs: every rank consumes the SHARED generators identically (they also produce the index stream,
+        # which must stay the same on all ranks) by drawing the noise of the GLOBAL batch and keeping its own rows
+        # [rank*B, (rank+1)*B) -- so row i of one shard never shares eps or a dropout pattern with row i of another, and
+        # the N-rank step is the single-process step on the global batch with the same draws.
+        W, r = (self.world.world_size, self.world.rank) if self.world is not None else (1, 0)
+        own = slice(r * B, (r + 1) * B)
         if self.rng_mode == "reference":
             def cpu_mask(shape):
-                m = torch.nn.functional.dropout(torch.ones(shape), self.dr_rate, True)
-                return (m != 0).to(torch.uint8).to(device)
+                m = torch.nn.functional.dropout(torch.ones((W * shape[0], shape[1])), self.dr_rate, True)
+                return (m[own] != 0).to(torch.uint8).contiguous().to(device)
             if training:
                 for n, s in shapes[:nh]:
                     masks[n] = cpu_mask(s)
-            eps = torch.empty(B, self.latent_dim).normal_().to(device)
+            eps = torch.empty(W * B, self.latent_dim).normal_()[own].contiguous().to(device)
             if training:
                 for n, s in shapes[nh:] + cls_shapes:
                     masks[n] = cpu_mask(s)
         else:
-            eps = torch.randn(B, self.latent_dim, device=device)
+            eps = torch.randn(W * B, self.latent_dim, device=device)
+            if W > 1:
+                eps = eps[own].contiguous()
             allshapes = shapes + cls_shapes
             if training and allshapes:
-                # every mask of the step from one Philox launch into one flat buffer (16-byte aligned slices)
+                # every mask of the step from one Philox launch into one flat buffer (16-byte aligned slices); the
+                # counter range of a step is cut into one stretch per rank
                 sizes = [(s[0] * s[1] + 15) // 16 * 16 for _, s in allshapes]
                 total = sum(sizes)
                 flat = self.__dict__.get("_mask_buf")
@@ -400,8 +424,9 @@ class Celligner2(nn.Module):
                     self.__dict__["_mask_buf"] = flat
                     self.__dict__["_mask_seed"] = torch.initial_seed()
                     self.__dict__["_mask_offset"] = 0
-                ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"], self.__dict__["_mask_offset"])
-                self.__dict__["_mask_offset"] += total // 16
+                ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"],
+                                  self.__dict__["_mask_offset"] + r * (total // 16))
+                self.__dict__["_mask_offset"] += W * (total // 16)
                 o = 0
                 for (n, s), sz in zip(allshapes, sizes):
                     masks[n] = flat[o:o + s[0] * s[1]].view(s)
@@ -416,6 +441,9 @@ class Celligner2(nn.Module):
         xin (encoder input already transformed), lgx1 (data-only NB term), and x_full / goodloc_full / row_index
         (the batch's counts are rows `row_index` of the resident matrices; x itself is then not needed), and
         xin_full / row_index32 instead of xin (the encoder input is read in place from the resident bf16 matrix)."""
+        if weight is not None:
+            raise NotImplementedError("per-sample `weight` (the reference passes it to the classifier's BCE, "
+                                      "losses.py:318-333; its loader always delivers None) is outside the path")
         if x is None:
             if x_full is None or row_index is None or (xin is None and xin_full is None) or sizefactor is None:
                 raise ValueError("forward needs x, or x_full + row_index + xin (or xin_full + row_index32) + sizefactor "

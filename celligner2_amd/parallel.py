@@ -119,6 +119,7 @@ class DataParallelStep:
         wait_deferred() before it touches that bucket -- the optimizer overlaps the exposed tail of the exchange."""
         pend = self._pending
         self._pending = []
+        self.wait_deferred()  # never replace a bucket that is still in flight without ordering after it
         if self.defer_last and len(pend) > 1:
             self._deferred = pend.pop()
         for ev, _, _ in pend:

@@ -260,6 +260,14 @@ class Trainer:
             self.dataloader_valid = _Loader(self.valid_data, val_bs, None, None, self.rng, xin_dtype, log_in, self.world,
                                             nbc, rx)
 
+    def make_optimizer(self, lr=1e-3, eps=0.01):
+        """trainer.py:262-266: Adam over the parameters that require a gradient, L2 weight decay; here the fused
+        multi-tensor kernel, wired to the engine's operand copies and (data-parallel runs) to the gradient exchange."""
+        lookup, updated = self.model._adam_hooks()
+        return FusedAdam([p for p in self.model.parameters() if p.requires_grad], lr=lr, eps=eps,
+                         weight_decay=self.weight_decay, clip_value=self.clip_value, shadow_lookup=lookup,
+                         on_updated=updated, grad_sync=self.world)
+
     def calc_alpha_coeff(self):
         """trainer.py:231-253."""
         if self.alpha_epoch_anneal is not None:
@@ -275,12 +283,7 @@ class Trainer:
         self.model.train()
         self.n_epochs = n_epochs
         eng = self.model._engine()
-        names = {id(p): n for n, p in self.model.named_parameters()}
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        lookup, updated = self.model._adam_hooks()
-        self.optimizer = FusedAdam(params, lr=lr, eps=eps, weight_decay=self.weight_decay,
-                                   clip_value=self.clip_value,
-                                   shadow_lookup=lookup, on_updated=updated, grad_sync=getattr(self, "world", None))
+        self.optimizer = self.make_optimizer(lr, eps)
         self.before_loop()
         for self.epoch in range(n_epochs):
             self.on_epoch_begin(lr, eps)

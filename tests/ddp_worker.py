@@ -21,6 +21,8 @@ def main():
     from celligner2_amd.parallel import DataParallelStep
     from oracle import c2_oracle as orc
 
+    if len(sys.argv) > 1 and sys.argv[1] == "noise":
+        return noise_variant(rank, world)
     use_bn = len(sys.argv) > 1 and sys.argv[1] == "bn"
     global NSTEPS
     NSTEPS = 6
@@ -96,6 +98,60 @@ def main():
                 ok = False
                 print("MISMATCH param after Adam", n, err)
         print("losses ddp", losses, "single", ref_l)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1.0 else 1)
+
+
+def noise_variant(rank, world):
+    """eps and dropout masks of a data-parallel step: different on every rank (rows of ONE global draw), while the
+    shared generators stay in lock-step (the index stream must be the same on all ranks)."""
+    from celligner2_amd.model import Celligner2
+    from celligner2_amd.parallel import DataParallelStep
+
+    B, L = 32, 8
+    ok = True
+    for mode in ("reference", "device"):
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        m = Celligner2(64, [48, 24], L, 0.2, False, "nb", conditions=["a", "b"], predictors=["p", "q"]).cuda().train()
+        m.rng_mode = mode
+        comm = DataParallelStep()
+        comm.attach_model(m)
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        eps, masks = m._draw_noise(B, True, torch.device("cuda", 0))
+        eps2, masks2 = m._draw_noise(B, True, torch.device("cuda", 0))  # a second step: fresh draws
+        after = torch.randperm(50).tolist() if mode == "reference" else torch.randperm(50, device="cuda").tolist()
+        mine = dict(eps=eps.cpu().numpy(), eps2=eps2.cpu().numpy(), after=after,
+                    masks={k: v.cpu().numpy() for k, v in masks.items()},
+                    masks2={k: v.cpu().numpy() for k, v in masks2.items()})
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        if rank == 0:
+            a, b = got[0], got[1]
+            assert sorted(a["masks"]) == ["cls.D0", "dec.D0", "dec.D1", "enc.D0", "enc.D1"], sorted(a["masks"])
+            ok &= a["eps"].shape == (B, L) and not np.allclose(a["eps"], b["eps"])
+            ok &= not np.allclose(a["eps"], a["eps2"])
+            for k in a["masks"]:
+                ok &= a["masks"][k].shape == b["masks"][k].shape and not np.array_equal(a["masks"][k], b["masks"][k])
+                ok &= not np.array_equal(a["masks"][k], a["masks2"][k]) and not np.array_equal(a["masks2"][k], b["masks"][k])
+                keep = a["masks"][k].mean()
+                ok &= bool(0.7 < keep < 0.9)
+            ok &= a["after"] == b["after"]  # generators in lock-step
+            if mode == "reference":  # the ranks hold the rows of the single-process draw on the global batch
+                torch.manual_seed(5)
+                m1 = Celligner2(64, [48, 24], L, 0.2, False, "nb", conditions=["a", "b"], predictors=["p", "q"])
+                torch.manual_seed(5)
+                m1.train()
+                m1.rng_mode = "reference"
+                e1, k1 = m1._draw_noise(world * B, True, torch.device("cuda", 0))
+                ok &= np.array_equal(e1.cpu().numpy(), np.concatenate([g["eps"] for g in got]))
+                for k in k1:
+                    ok &= np.array_equal(k1[k].cpu().numpy(), np.concatenate([g["masks"][k] for g in got]))
+            if not ok:
+                print("MISMATCH noise variant, mode", mode)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

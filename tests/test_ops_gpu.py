@@ -516,6 +516,31 @@ def test_adam_matches_oracle():
         assert torch.equal(sh[k], tp[k].to(torch.bfloat16))
 
 
+def test_adam_many_tensors_with_an_empty_one():
+    """More tensors than one launch's table holds (48), an empty one among them (theta is [G,0] without conditions):
+    every tensor is updated exactly once per step."""
+    ops = _ops()
+    rng = np.random.default_rng(10)
+    shapes = [(3 + i % 5, 2 + i % 3) for i in range(60)]
+    shapes[7] = (11, 0)
+    shapes[52] = (0,)
+    params = {f"p{i:02d}": rng.standard_normal(s).astype(np.float32) for i, s in enumerate(shapes)}
+    tp = {k: T(v.copy()) for k, v in params.items()}
+    tm = {k: torch.zeros_like(v) for k, v in tp.items()}
+    tv = {k: torch.zeros_like(v) for k, v in tp.items()}
+    state = {}
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    for step in range(1, 3):
+        grads = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in params.items()}
+        orc.adam_step(p64, {k: g.astype(np.float64) for k, g in grads.items()}, state)
+        tg = {k: T(g) for k, g in grads.items()}
+        ops.adam_step([(tp[k], tg[k], tm[k], tv[k], None) for k in tp], 1e-3, 0.9, 0.999, 0.01, 0.04, 0.0, step)
+    for k in tp:
+        if tp[k].numel():
+            assert rel(tp[k], p64[k]) < 1e-6, k
+            assert rel(tm[k], state[k][0]) < 1e-5 and rel(tv[k], state[k][1]) < 1e-5, k
+
+
 def test_prep_and_gather():
     ops = _ops()
     rng = np.random.default_rng(2)
