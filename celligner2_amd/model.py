@@ -131,6 +131,8 @@ def _keep_accumulated(model, eng):
     lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
     for p in model._param_list:
         if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+            if eng.comm is not None:
+                eng.comm.wait_deferred()  # the bucket an earlier backward left in flight must have landed first
             p.grad = p.grad.clone()
 
 

@@ -26,12 +26,14 @@ class DataParallelStep:
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
-        self.world_size = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self._setup(dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group) != "nccl")
+
+    def _setup(self, world_size, rank, host_backend):
+        self.world_size, self.rank = world_size, rank
         # gloo (CPU tests, rehearsals with several ranks on one GPU): device tensors are exchanged through explicit host
         # copies (gloo's own handling of device tensors was seen to stall after a few steps with ranks sharing a GPU).
         # RCCL ("nccl") is stream-ordered and takes the asynchronous path.
-        self._host_backend = dist.get_backend(group) != "nccl"
+        self._host_backend = host_backend
         self._side = None
         self._pending = []
         self.defer_last = False  # set by the optimizer wiring: the last bucket's wait moves into FusedAdam.step
@@ -54,28 +56,31 @@ class DataParallelStep:
         start = sum(sizes[: self.rank])
         return start, start + sizes[self.rank]
 
+    # -- the two primitives every collective below is made of (a test double overrides exactly these)
+    def _sum_(self, t):
+        """In-place SUM over ranks, enqueued on the current stream (RCCL) or blocking (gloo on host tensors)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _gather0(self, t):
+        """Every rank's `t` concatenated along dim 0 in rank order."""
+        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
     # -- forward collectives
     def allgather_rows(self, feat, cond):
         """[B,D] fp32 / [B,C] int64 of every rank stacked in rank order (equal B on all ranks)."""
         if self._host_backend and feat.is_cuda:
             return self._host_gather(feat), self._host_gather(cond)
-        B = feat.shape[0]
-        feat_all = torch.empty((self.world_size * B,) + tuple(feat.shape[1:]), dtype=feat.dtype, device=feat.device)
-        cond_all = torch.empty((self.world_size * B,) + tuple(cond.shape[1:]), dtype=cond.dtype, device=cond.device)
-        dist.all_gather_into_tensor(feat_all, feat.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(cond_all, cond.contiguous(), group=self.group)
-        return feat_all, cond_all
+        return self._gather0(feat), self._gather0(cond)
 
     # gloo with device tensors: the exchange is made on host copies (blocking), explicitly
     def _host_gather(self, t):
-        h = t.detach().contiguous().cpu()
-        out = torch.empty((self.world_size * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
-        dist.all_gather_into_tensor(out, h, group=self.group)
-        return out.to(t.device)
+        return self._gather0(t.detach().contiguous().cpu()).to(t.device)
 
     def _host_reduce(self, t):
         h = t.detach().contiguous().cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum_(h)
         t.copy_(h.to(t.device).view_as(t))
         return t
 
@@ -83,15 +88,12 @@ class DataParallelStep:
         """[2,H] fp32 statistics partial of every rank stacked in rank order -> [world,2,H]."""
         if self._host_backend and part.is_cuda:
             return self._host_gather(part).view((self.world_size,) + tuple(part.shape))
-        out = torch.empty((self.world_size * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype,
-                          device=part.device)  # the flat "concatenate along dim 0" form every backend takes
-        dist.all_gather_into_tensor(out, part.contiguous(), group=self.group)
-        return out.view((self.world_size,) + tuple(part.shape))
+        return self._gather0(part).view((self.world_size,) + tuple(part.shape))
 
     def allreduce_scalars(self, t):
         if self._host_backend and t.is_cuda:
             return self._host_reduce(t)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum_(t)
         return t
 
     # -- backward collectives
@@ -106,12 +108,12 @@ class DataParallelStep:
             ev.record(torch.cuda.current_stream(flat.device))
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                self._sum_(flat)
                 done = torch.cuda.Event()
                 done.record(self._side)
             self._pending.append((done, flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum_(flat)
 
     def wait_all(self):
         """Order the compute stream after the bucket all-reduces.  With `defer_last`, the newest bucket (the encoder's

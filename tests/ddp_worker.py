@@ -122,6 +122,7 @@ def noise_variant(rank, world):
         torch.manual_seed(5)
         torch.cuda.manual_seed(5)
         eps, masks = m._draw_noise(B, True, torch.device("cuda", 0))
+        eps, masks = eps.clone(), {k: v.clone() for k, v in masks.items()}  # (the device masks are views of one buffer)
         eps2, masks2 = m._draw_noise(B, True, torch.device("cuda", 0))  # a second step: fresh draws
         after = torch.randperm(50).tolist() if mode == "reference" else torch.randperm(50, device="cuda").tolist()
         mine = dict(eps=eps.cpu().numpy(), eps2=eps2.cpu().numpy(), after=after,
@@ -131,15 +132,22 @@ def noise_variant(rank, world):
         dist.all_gather_object(got, mine)
         if rank == 0:
             a, b = got[0], got[1]
+            bad = []
+
+            def chk(what, cond):
+                if not bool(cond):
+                    bad.append(what)
+
             assert sorted(a["masks"]) == ["cls.D0", "dec.D0", "dec.D1", "enc.D0", "enc.D1"], sorted(a["masks"])
-            ok &= a["eps"].shape == (B, L) and not np.allclose(a["eps"], b["eps"])
-            ok &= not np.allclose(a["eps"], a["eps2"])
+            chk("eps differs between ranks", a["eps"].shape == (B, L) and not np.allclose(a["eps"], b["eps"]))
+            chk("eps differs between steps", not np.allclose(a["eps"], a["eps2"]))
             for k in a["masks"]:
-                ok &= a["masks"][k].shape == b["masks"][k].shape and not np.array_equal(a["masks"][k], b["masks"][k])
-                ok &= not np.array_equal(a["masks"][k], a["masks2"][k]) and not np.array_equal(a["masks2"][k], b["masks"][k])
-                keep = a["masks"][k].mean()
-                ok &= bool(0.7 < keep < 0.9)
-            ok &= a["after"] == b["after"]  # generators in lock-step
+                chk(k + " differs between ranks",
+                    a["masks"][k].shape == b["masks"][k].shape and not np.array_equal(a["masks"][k], b["masks"][k]))
+                chk(k + " differs between steps", not np.array_equal(a["masks"][k], a["masks2"][k]))
+                chk(k + " rank 0 step 2 differs from rank 1 step 1", not np.array_equal(a["masks2"][k], b["masks"][k]))
+                chk(k + f" keep rate {a['masks'][k].mean():.3f}", 0.7 < a["masks"][k].mean() < 0.9)
+            chk("generators in lock-step after the draws", a["after"] == b["after"])
             if mode == "reference":  # the ranks hold the rows of the single-process draw on the global batch
                 torch.manual_seed(5)
                 m1 = Celligner2(64, [48, 24], L, 0.2, False, "nb", conditions=["a", "b"], predictors=["p", "q"])
@@ -147,11 +155,13 @@ def noise_variant(rank, world):
                 m1.train()
                 m1.rng_mode = "reference"
                 e1, k1 = m1._draw_noise(world * B, True, torch.device("cuda", 0))
-                ok &= np.array_equal(e1.cpu().numpy(), np.concatenate([g["eps"] for g in got]))
+                chk("eps = rows of the global draw", np.array_equal(e1.cpu().numpy(), np.concatenate([g["eps"] for g in got])))
                 for k in k1:
-                    ok &= np.array_equal(k1[k].cpu().numpy(), np.concatenate([g["masks"][k] for g in got]))
-            if not ok:
-                print("MISMATCH noise variant, mode", mode)
+                    chk(k + " = rows of the global draw",
+                        np.array_equal(k1[k].cpu().numpy(), np.concatenate([g["masks"][k] for g in got])))
+            if bad:
+                ok = False
+                print("MISMATCH noise variant, mode", mode, bad)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

@@ -337,3 +337,51 @@ def test_bf16_operand_copies_follow_the_optimizer():
         m.__dict__["_eng"] = None
         fresh = [t.item() for t in m(x=x, batch=cond, sizefactor=x.sum(1))]
     assert kept == fresh
+
+
+def test_one_workspace_guards_stale_forward_accumulation_weight_and_sticky_status():
+    """The engine keeps ONE workspace per model.  (1) A backward whose forward has been overwritten by a later training
+    forward raises instead of differentiating the wrong activations; a no-grad (validation) forward in between is
+    harmless.  (2) Gradient accumulation / zero_grad(set_to_none=False) give sums, not aliases.  (3) `weight` is
+    refused, not ignored.  (4) A bad condition value in ANY batch of an epoch is still reported at the epoch's end
+    (status words are sticky), once."""
+    z, meta = gu.load("nb_basic")
+    model = build_model(meta, z, "fp32")
+    batch_np = gu.group(z, "batch/")
+    mk = lambda: {k: torch.tensor(v).to(DEV) for k, v in batch_np.items()}  # noqa: E731
+    model._forced_noise = dict(eps=torch.tensor(z["s0/eps"]).to(DEV), masks={})
+    r1, k1, m1, c1 = model(**mk())
+    r2, k2, m2, c2 = model(**mk())
+    with pytest.raises(RuntimeError, match="saved activations have been overwritten"):
+        (r1 + k1).backward()
+    with torch.no_grad():
+        model(**mk())  # a validation-style forward keeps the saved activations of forward 2
+    (r2 + 1e-3 * k2 + m2 + c2).backward()
+    single = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    for n, g in gu.group(z, "s0/grad/").items():
+        assert gu.grad_err(n, single[n].cpu().numpy(), g, gu.cfg_from_meta(meta), gu.group(z, "s0/grad/")) < 1e-4, n
+    # accumulate a second backward on top of the handed-over views
+    r, k, m, c = model(**mk())
+    (r + 1e-3 * k + m + c).backward()
+    for n, p in model.named_parameters():
+        if n in single:
+            assert torch.allclose(p.grad, 2 * single[n], rtol=1e-6, atol=1e-12), n
+    model.zero_grad(set_to_none=False)
+    r, k, m, c = model(**mk())
+    (r + 1e-3 * k + m + c).backward()
+    for n, p in model.named_parameters():
+        if n in single:
+            assert torch.allclose(p.grad, single[n], rtol=1e-6, atol=1e-12), n
+    with pytest.raises(NotImplementedError):
+        model(weight=torch.ones(3, device=DEV), **mk())
+    # sticky status
+    eng = model._engine()
+    eng.check_status()
+    bad = mk()
+    bad["batch"][0, 0] = 2
+    with torch.no_grad():
+        model(**bad)
+        model(**mk())  # a later, clean batch must not erase the report
+    with pytest.raises(IndexError):
+        eng.check_status()
+    eng.check_status()  # reported once, then clear
