@@ -65,6 +65,8 @@ _SIGS = {
     "c2_partition": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "c2_mmd_ws": (sz, [i64, i64, i64]),
     "c2_mmd_fwd_bwd": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp, vp]),
+    "c2_mmd_static_floats": (sz, []),
+    "c2_mmd_fwd_bwd_static": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp]),
     "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f64, f64, f64, f64, f64, f64, i64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,

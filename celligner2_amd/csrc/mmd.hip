@@ -10,6 +10,7 @@
 // Rows may be a local shard [row0,row0+Bl) against the all-gathered Bg rows (data-parallel MMD): by symmetry of K
 // the local rows' full gradient needs only their own row block, so no backward collective exists.
 #include "common.h"
+#include <mutex>
 
 namespace c2 {
 
@@ -749,9 +750,11 @@ extern "C" size_t c2_mmd_ws(int64_t Bl, int64_t Bg, int64_t D) {
     return (size_t)(Bg + kReduceWsFloats + (int64_t)jsplit * Bl * D + 64);
 }
 
-extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
-                              int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out,
-                              float* dfeat, int64_t lddf, float* ws, void* stream) {
+// Launch sequence shared by c2_mmd_fwd_bwd (caller-owned workspace) and c2_mmd_fwd_bwd_static (the library's own
+// file-scope scratch array): `ws` is a DEVICE pointer to >= c2_mmd_ws(Bl,Bg,D) floats, all of it written before read.
+static int mmd_run(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
+                   int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out,
+                   float* dfeat, int64_t lddf, float* ws, void* stream) {
     C2_CHECK(feat && part_id && wt && loss_out && dfeat && ws, "null pointer");
     C2_CHECK(f_dtype == C2_F32 || f_dtype == C2_BF16, "bad dtype");
     C2_CHECK(ldf >= D && lddf >= D && row0 >= 0 && row0 + Bl <= Bg, "bad shape");
@@ -787,4 +790,56 @@ extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const 
     launch_finalize_sum(partials, nit * jsplit, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
+                              int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out,
+                              float* dfeat, int64_t lddf, float* ws, void* stream) {
+    return mmd_run(feat, f_dtype, ldf, part_id, wt, row0, Bl, Bg, D, beta, loss_out, dfeat, lddf, ws, stream);
+}
+
+// ---- the entry point that allocates nothing --------------------------------------------------------------------
+// The MMD's scratch (row norms, loss partials, gradient slabs) in a file-scope device array instead of a caller
+// workspace.  `scratch` is a HOST-side stand-in for the array: only the address hipGetSymbolAddress returns for the
+// CURRENT device may reach a kernel, and every GPU holds its own copy at its own address.
+static __device__ __align__(256) float scratch[C2_MMD_STATIC_FLOATS];
+
+constexpr int kMaxDevices = 64;
+static float* g_scratch_dev[kMaxDevices];  // per device: address of that GPU's copy of `scratch` (0 = not asked yet)
+static std::mutex g_scratch_mu;
+
+// Address of the current device's scratch array; looked up once per device, with that device current.
+static int scratch_on_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    C2_CHECK(e == hipSuccess, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    C2_CHECK(dev >= 0 && dev < kMaxDevices, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_dev[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        C2_CHECK(e == hipSuccess && p, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_dev[dev] = p;
+    }
+    *out = g_scratch_dev[dev];
+    return 0;
+}
+
+extern "C" size_t c2_mmd_static_floats(void) { return (size_t)C2_MMD_STATIC_FLOATS; }
+
+extern "C" int c2_mmd_fwd_bwd_static(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id,
+                                     const float* wt, int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta,
+                                     float* loss_out, float* dfeat, int64_t lddf, void* stream) {
+    C2_CHECK(Bl >= 0 && Bg >= 0 && D >= 0, "negative size");
+    const size_t need = c2_mmd_ws(Bl, Bg, D);
+    C2_CHECK(need <= (size_t)C2_MMD_STATIC_FLOATS,
+             "MMD of " + std::to_string(Bl) + " x " + std::to_string(Bg) + " rows, " + std::to_string(D) +
+                 " features needs " + std::to_string(need) + " floats of scratch; the static array holds " +
+                 std::to_string((size_t)C2_MMD_STATIC_FLOATS) + " (C2_MMD_STATIC_FLOATS): use c2_mmd_fwd_bwd with a "
+                 "caller workspace");
+    float* ws = nullptr;
+    if (int rc = scratch_on_current_device(&ws)) return rc;
+    // Nothing of the array has to start at zero: row norms [Bg], loss partials [nit*jsplit] and gradient slabs
+    // [jsplit][Bl][D] are each fully written by this call's kernels before its reducing kernels read them.
+    return mmd_run(feat, f_dtype, ldf, part_id, wt, row0, Bl, Bg, D, beta, loss_out, dfeat, lddf, ws, stream);
 }

@@ -462,6 +462,21 @@ def mmd(feat, part_id, wt, row0, Bl, beta, loss_out, dfeat, ws):
                              int(Bl), Bg, D, float(beta), ptr(loss_out), ptr(dfeat), D, ptr(ws), stream()))
 
 
+def mmd_static_capacity():
+    """Floats of the library's static MMD scratch array (include/c2mi.h: C2_MMD_STATIC_FLOATS)."""
+    return int(lib.c2_mmd_static_floats())
+
+
+def mmd_static(feat, part_id, wt, row0, Bl, beta, loss_out, dfeat):
+    """mmd() on the library's file-scope scratch array: no workspace argument, no allocation of any kind.  Raises
+    C2Error when mmd_ws(Bl, Bg, D) exceeds mmd_static_capacity().  Calls overlapping on one GPU race (shared array)."""
+    L.require_gpu(feat, part_id, wt, dfeat)
+    Bg, D = feat.shape
+    assert dfeat.is_contiguous() and tuple(dfeat.shape) == (Bl, D)
+    check(lib.c2_mmd_fwd_bwd_static(ptr(feat), dt_code(feat.dtype), _row_major(feat, "feat"), ptr(part_id), ptr(wt),
+                                    int(row0), int(Bl), Bg, D, float(beta), ptr(loss_out), ptr(dfeat), D, stream()))
+
+
 def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
     """entries: list of (p, g, m, v, shadow_or_None) contiguous fp32 tensors; shadow: a bf16 copy of p's shape, or the
     [2, *p.shape] bf16 planes (hi, lo) of a C2_BF16X3P operand."""

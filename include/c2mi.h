@@ -208,6 +208,20 @@ int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* pa
                    int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out, float* dfeat,
                    int64_t lddf, float* ws, void* stream);
 
+/* The entry point that allocates nothing and takes no workspace: c2_mmd_fwd_bwd with its scratch (row norms, loss
+ * partials, gradient slabs) in a file-scope device array of C2_MMD_STATIC_FLOATS floats (4 MiB, held by every GPU the
+ * library runs on until the process ends).  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate or carry a workspace -- code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, results bit-identical to c2_mmd_fwd_bwd.  Sizes whose c2_mmd_ws(Bl,Bg,D) exceeds
+ * C2_MMD_STATIC_FLOATS are rejected with an error (e.g. 512 x 512 rows x 64 features or 1024 x 1024 x 16 fit, 4096 x
+ * 4096 x 64 does not).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * host threads) race; calls on one stream are ordered and safe.  Calls no hipMalloc / hipFree and launches on `stream`. */
+#define C2_MMD_STATIC_FLOATS (1u << 20)
+size_t c2_mmd_static_floats(void);
+int c2_mmd_fwd_bwd_static(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,
+                          int64_t row0, int64_t Bl, int64_t Bg, int64_t D, float beta, float* loss_out, float* dfeat,
+                          int64_t lddf, void* stream);
+
 /* torch.optim.Adam step as trainer.py:262-266,316-323 configures it (L2 weight decay added to the gradient,
  * optional clip_grad_value_), over a table of tensors.  desc_host: array of n c2_adam_tensor (HOST memory,
  * copied by value into the launch).  step_t >= 1.  shadow (bf16 copy of the updated weights, may be NULL; with
