@@ -16,43 +16,54 @@ from . import ops
 
 
 def label_encoder_2D(adata, encoder, label_sets):
-    """dataset/celligner2/_utils.py:39-77: multi-hot matrix, -1 for labels missing from the encoder."""
-    labels = np.zeros((adata.shape[0], len(encoder.keys())))
-    miss = set()
-    for label_key in label_sets.keys():
-        unique_conditions = list(np.unique(adata.obs[label_key]))
-        if not set(unique_conditions).issubset(set(encoder.keys())):
-            miss = miss | set(unique_conditions) - set(encoder.keys())
-            print(f"Warning: Labels: {miss} in adata.obs[{label_key}] is not a subset of label-encoder!")
-            print("Therefore integer value of those labels is set to -1")
-    for k, values in label_sets.items():
-        for val in values:
-            sel = np.asarray(adata.obs[k] == val)
-            if val in miss:
-                for toset in set(values) - miss:
-                    labels[sel, encoder[toset]] = -1
-            else:
-                labels[sel, encoder[val]] = 1
-    return labels
+    """Multi-hot label matrix [n, len(encoder)] of the obs columns `label_sets` (column name -> the values it holds):
+    1 in the column of every label a row carries; a row whose label in column k is NOT in the encoder gets -1 in the
+    columns of all of k's known labels (the reference's marker for "missing": dataset/celligner2/_utils.py:39-77)."""
+    n = adata.shape[0]
+    out = np.zeros((n, len(encoder)))
+    columns = {key: np.asarray(adata.obs[key]).astype(object) for key in label_sets}
+    unknown = set()
+    for key, col in columns.items():
+        extra = set(col) - set(encoder)
+        if extra:
+            unknown |= extra
+            print(f"Note: obs[{key!r}] holds labels the encoder does not know ({sorted(map(str, unknown))}); "
+                  "rows carrying them are marked -1 in that column's labels")
+    rows = np.arange(n)
+    for key, values in label_sets.items():
+        known = [v for v in values if v not in unknown]
+        if not known:
+            continue
+        where = np.array([encoder[v] for v in known], dtype=np.int64)
+        slot = {v: i for i, v in enumerate(known)}
+        pos = np.fromiter((slot.get(v, -1) for v in columns[key]), dtype=np.int64, count=n)  # -1: unknown label
+        hit = pos >= 0
+        out[rows[hit], where[pos[hit]]] = 1
+        if (~hit).any():
+            out[np.ix_(rows[~hit], where)] = -1
+    return out
 
 
 def train_test_split(adata, train_frac=0.85, cell_type_key=None):
-    """trainers/celligner2/_utils.py:79-116 (numpy GLOBAL rng, optionally per cell type)."""
+    """Row indices (train, validation).  The cut is made per group -- the whole table, or one group per value of
+    obs[cell_type_key] in order of first appearance -- after ONE `np.random.shuffle` of the group's ascending row
+    indices: numpy's GLOBAL generator, consumed exactly as the reference consumes it
+    (trainers/celligner2/_utils.py:79-116), so a seeded run splits the same way.  train_frac == 1: no validation set."""
+    n = adata.shape[0]
     if train_frac == 1:
-        return np.arange(adata.shape[0]), None
-    indices = np.arange(adata.shape[0])
-    if cell_type_key is not None:
-        train_idx, val_idx = [], []
-        for cell_type in adata.obs[cell_type_key].unique().tolist():
-            ct_idx = indices[np.asarray(adata.obs[cell_type_key] == cell_type)]
-            n_train = int(np.ceil(train_frac * len(ct_idx)))
-            np.random.shuffle(ct_idx)
-            train_idx.append(ct_idx[:n_train])
-            val_idx.append(ct_idx[n_train:])
-        return np.concatenate(train_idx), np.concatenate(val_idx)
-    n_train = int(np.ceil(train_frac * len(indices)))
-    np.random.shuffle(indices)
-    return indices[:n_train], indices[n_train:]
+        return np.arange(n), None
+    if cell_type_key is None:
+        groups = [np.arange(n)]
+    else:
+        labels = adata.obs[cell_type_key]
+        groups = [np.flatnonzero(np.asarray(labels == value)) for value in labels.unique().tolist()]
+    kept, held = [], []
+    for members in groups:
+        np.random.shuffle(members)
+        cut = int(np.ceil(train_frac * members.size))
+        kept.append(members[:cut])
+        held.append(members[cut:])
+    return np.concatenate(kept), np.concatenate(held)
 
 
 class DeviceDataset:
@@ -109,18 +120,23 @@ class DeviceDataset:
 
     @property
     def stratifier_weights(self):
-        """anndata.py:137-166 (note: -1 entries count as present, as in the reference)."""
-        strat = np.zeros(self.n).astype(float)
-        mats = [m.T for m in (getattr(self, "conditions_np", None), getattr(self, "predictors_np", None))
-                if m is not None]
-        for mat in mats:
-            w = []
-            for i in range(mat.shape[0]):
-                cnt = np.count_nonzero(mat[i])
-                w.append(0 if cnt == 0 else 1 / (cnt * mat.shape[0]))
-            for i in range(mat.shape[0]):
-                strat += np.where(mat[i], w[i], 0)
-        return strat + self.minweight
+        """Sampling weight per row (dataset/celligner2/anndata.py:137-166): every label column of the condition and
+        predictor matrices shares 1/(number of columns) of its matrix equally among the rows whose entry is non-zero
+        (a -1 "missing" entry counts as present, as in the reference), plus `minweight`.  The per-row total is
+        accumulated column by column, conditions first (a running sum, so the float64 result has the reference's bits:
+        the index stream drawn from these weights is compared with the reference's)."""
+        tables = []
+        for name in ("conditions_np", "predictors_np"):
+            m = getattr(self, name, None)
+            if m is None or m.shape[1] == 0:
+                continue
+            present = m != 0
+            count = present.sum(0)
+            share = np.where(count > 0, 1.0 / (np.maximum(count, 1) * m.shape[1]), 0.0)
+            tables.append(np.where(present, share[None, :], 0.0))
+        if not tables:
+            return np.zeros(self.n) + self.minweight
+        return np.cumsum(np.concatenate(tables, 1), axis=1)[:, -1] + self.minweight
 
     @property
     def nb_row_const(self):
@@ -196,23 +212,17 @@ class DeviceDataset:
 
 def make_dataset(adata, train_frac=0.9, condition_keys=None, cell_type_key=None, condition_encoder=None,
                  cell_type_encoder=None, predictor_keys=None, predictor_encoder=None, min_weight=0.0, device="cuda"):
-    """trainers/celligner2/_utils.py:119-185."""
+    """(train, validation) DeviceDatasets of an AnnData-like object, prepared as the reference prepares them
+    (trainers/celligner2/_utils.py:119-185): NaN entries are remembered in the `goodloc` mask and replaced IN PLACE
+    (adata.X) by the NaN-mean of their gene over all rows; the per-row sum of the imputed matrix becomes
+    obs["celligner2_size_factors"]; then the split."""
     X = adata.X
-    goodloc = ~np.isnan(X)
-    if np.isnan(X).any():
-        nanme = np.nanmean(X, axis=0)
-        for i, val in enumerate(np.isnan(X).T):
-            X[val, i] = nanme[i]
-    size_factors = X.sum(1)
-    if len(size_factors.shape) < 2:
-        size_factors = np.expand_dims(size_factors, axis=1)
-    adata.obs["celligner2_size_factors"] = size_factors
-    train_idx, val_idx = train_test_split(adata, train_frac, cell_type_key)
-    kw = dict(condition_keys=condition_keys, cell_type_key=cell_type_key, condition_encoder=condition_encoder,
-              cell_type_encoder=cell_type_encoder, predictor_encoder=predictor_encoder, predictor_keys=predictor_keys,
-              minweight=min_weight, device=device)
-    train = DeviceDataset(adata[train_idx, :], goodloc[train_idx, :], **kw)
-    if train_frac == 1:
-        return train, None
-    valid = DeviceDataset(adata[val_idx, :], goodloc[val_idx, :], **kw)
-    return train, valid
+    missing = np.isnan(X)
+    if missing.any():
+        X[missing] = np.take(np.nanmean(X, axis=0), np.nonzero(missing)[1])
+    adata.obs["celligner2_size_factors"] = X.sum(1).reshape(X.shape[0], -1)
+    common = dict(condition_keys=condition_keys, cell_type_key=cell_type_key, condition_encoder=condition_encoder,
+                  cell_type_encoder=cell_type_encoder, predictor_encoder=predictor_encoder, predictor_keys=predictor_keys,
+                  minweight=min_weight, device=device)
+    parts = train_test_split(adata, train_frac, cell_type_key)
+    return tuple(None if rows is None else DeviceDataset(adata[rows, :], ~missing[rows, :], **common) for rows in parts)

@@ -118,46 +118,43 @@ def load(dir_path, device="cuda", precision="fp32"):
 
 
 def load_expand_params(model: Celligner2, state_dict):
-    """_base.py:97-134: tensors whose size grew (new condition columns) keep their fresh values outside the loaded
-    block; a tensor may only grow; keys missing from the checkpoint keep the new model's values."""
-    load_sd = dict(state_dict)
-    device = next(model.parameters()).device
-    new_sd = model.state_dict()
-    for key, load_ten in state_dict.items():
-        new_ten = new_sd[key]
-        if new_ten.size() == load_ten.size():
+    """Load a checkpoint into a model that may have GROWN since (new condition columns in `theta [G,C]` and
+    `*.cond_L.weight [H,C]`): for every tensor of the model, in the model's own key order -- absent from the checkpoint:
+    keep the fresh value; same shape: take the checkpoint's; larger in some dimension: checkpoint values in the leading
+    block, fresh values elsewhere.  Shrinking, a change of rank or more than 3 dimensions is refused; keys the model does
+    not have make `load_state_dict` raise, as in the reference (_base.py:97-134)."""
+    fresh = model.state_dict()
+    merged = {k: v for k, v in state_dict.items() if k not in fresh}  # unexpected keys: left for load_state_dict to reject
+    for key, new in fresh.items():
+        old = state_dict.get(key)
+        if old is None or old.shape == new.shape:
+            merged[key] = new if old is None else old
             continue
-        load_ten = load_ten.to(device)
-        if new_ten.dim() != load_ten.dim():
-            raise ValueError(f"{key}: rank changed")
-        for i, val in enumerate(new_ten.shape):
-            if val < load_ten.shape[i]:
-                raise ValueError("Can only increase the size of the model for now")
-        if new_ten.dim() > 3:
+        if old.dim() != new.dim():
+            raise ValueError(f"{key}: rank changed from {old.dim()} to {new.dim()}")
+        if new.dim() > 3:
             raise ValueError("Too many dimensions")
-        new_ten = new_ten.clone()
-        new_ten[tuple(slice(0, n) for n in load_ten.shape)] = load_ten
-        load_sd[key] = new_ten
-    for key, ten in new_sd.items():
-        if key not in load_sd:
-            load_sd[key] = ten
-    model.load_state_dict(load_sd)
+        if any(o > n for o, n in zip(old.shape, new.shape)):
+            raise ValueError("Can only increase the size of the model for now")
+        grown = new.clone()
+        grown[tuple(slice(0, o) for o in old.shape)] = old.to(new.device)
+        merged[key] = grown
+    model.load_state_dict(merged)
     return model
 
 
+# parameter-name fragments that stay trainable after surgery (_base.py:342-354)
+_TRAINABLE_AFTER_SURGERY = {True: ("theta", "cond_L.weight"),   # freeze_expression: dispersion + condition weights only
+                            False: ("theta", "L0", "N0")}       # else: dispersion + every first layer and its norm
+
+
 def apply_freeze(model: Celligner2, freeze_expression=True):
-    """_base.py:342-354: train only theta and the condition weights (freeze_expression) or every first layer."""
+    """Surgery freeze: `model.freeze = True` and requires_grad only on the parameters whose NAME contains one of the
+    fragments above (matching by substring, as the reference does)."""
     model.freeze = True
+    keep = _TRAINABLE_AFTER_SURGERY[bool(freeze_expression)]
     for name, p in model.named_parameters():
-        p.requires_grad = False
-        if "theta" in name:
-            p.requires_grad = True
-        if freeze_expression:
-            if "cond_L.weight" in name:
-                p.requires_grad = True
-        else:
-            if "L0" in name or "N0" in name:
-                p.requires_grad = True
+        p.requires_grad = any(fragment in name for fragment in keep)
     return model
 
 

@@ -14,7 +14,7 @@ def step_cases():
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
-        if name.startswith("nb_wide_row") or name.startswith("trainer_"):
+        if name.startswith(("nb_wide_row", "trainer_", "surgery_")):
             continue
         out.append(name)
     return out
@@ -66,3 +66,44 @@ def grad_err(name, got, ref, cfg, all_ref):
         scale = max(np.abs(all_ref[name[:-4] + "weight"]).max(), np.abs(ref).max())
         return float(np.abs(np.asarray(got, np.float64) - ref).max() / scale)
     return relerr(got, ref)
+
+
+class AnnDataLike:
+    """Minimal AnnData stand-in (what the reference's trainer touches): .X ndarray, .obs DataFrame, row slicing."""
+
+    def __init__(self, X, obs):
+        self.X, self.obs = X, obs
+
+    @property
+    def shape(self):
+        return self.X.shape
+
+    @property
+    def n_vars(self):
+        return self.X.shape[1]
+
+    def __len__(self):
+        return self.X.shape[0]
+
+    def __getitem__(self, idx):
+        rows = np.asarray(idx[0] if isinstance(idx, tuple) else idx)
+        return AnnDataLike(self.X[rows], self.obs.iloc[rows].copy())
+
+
+def adata_from(z, x_key="X", obs_prefix="obs/"):
+    """The AnnData-like object a trainer_* / surgery_* fixture was generated from (a fresh copy)."""
+    import pandas as pd
+    cols = {k[len(obs_prefix):]: [str(v) for v in z[k]] for k in z.files if k.startswith(obs_prefix)}
+    n = len(next(iter(cols.values())))
+    return AnnDataLike(z[x_key].copy(), pd.DataFrame(cols, index=[f"s{i}" for i in range(n)]))
+
+
+def calls_of(z, prefix="calls/"):
+    """Per loss() call of the reference trainer: (train flag, rows, eps, lr, alpha, epoch)."""
+    size = z[prefix + "size"]
+    ends = np.cumsum(size)
+    out = []
+    for i, (e, n) in enumerate(zip(ends, size)):
+        out.append(dict(train=int(z[prefix + "train"][i]), rows=z[prefix + "rows"][e - n:e], eps=z[prefix + "eps"][e - n:e],
+                        lr=float(z[prefix + "lr"][i]), alpha=float(z[prefix + "alpha"][i]), epoch=int(z[prefix + "epoch"][i])))
+    return out

@@ -114,3 +114,25 @@ def load():
     ns.AnnotatedDataset = ds.AnnotatedDataset
     ns.AnnDataLike = AnnDataLike
     return ns
+
+
+def load_wrapper(ns=None):
+    """Adds the reference's AnnData-level wrapper class to the namespace: ns.CELLIGNER2
+    (celligner2/model/celligner2_model.py).  Two more harness patches, for that file only: the numpy-1.x private
+    name it imports is given a stand-in, and the `pdb.set_trace()` left in `_get_user_attributes`
+    (othermodels/base/_base.py:32-34) is a no-op."""
+    ns = ns or load()
+    import pdb
+
+    import numpy.lib
+
+    fb = sys.modules.get("numpy.lib.function_base") or types.ModuleType("numpy.lib.function_base")
+    if not hasattr(fb, "_percentile_dispatcher"):
+        fb._percentile_dispatcher = lambda *a, **k: None
+    sys.modules["numpy.lib.function_base"] = fb
+    numpy.lib.function_base = fb
+    pdb.set_trace = lambda *a, **k: None
+    ns.wrapper_mod = importlib.import_module("celligner2.model.celligner2_model")
+    ns.CELLIGNER2 = ns.wrapper_mod.CELLIGNER2
+    ns.base = importlib.import_module("celligner2.othermodels.base._base")
+    return ns
