@@ -5,6 +5,8 @@
 // accumulates in an LDS array across the workgroup's rows and leaves the kernel as one partial row per workgroup
 // (summed by a second tiny kernel: deterministic, no atomics).  HBM traffic per cell = logits 4G + x 4G +
 // goodloc 1G read, dlogits (2|4)G written: the algorithmic minimum.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace c2 {
@@ -56,9 +58,23 @@ __device__ __forceinline__ float digamma_pos(float z) {
 // pattern 0: the row holds only 0s  -> q = e0;  1: only 1s -> q = e1;  2: both -> q = e0 + e1
 // (celligner2/model/_utils.py:19-24 scatter_ quirk).  tab: [3][3][G] = {theta, K1, K2}
 //   K1 = theta*log(theta+eps) - lgamma(theta),  K2 = log(theta+eps) + theta/(theta+eps) - digamma(theta)
-__global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, float* __restrict__ tab) {
+// The table's rows are `Gp` apart, G rounded up to a multiple of 12 288 = lcm(4 x 1024, 4 x 768) (nb_tab_ld): the padding holds theta = 1,
+// K1 = K2 = 0, values on which the per-gene arithmetic stays finite, so that the fast kernel can read whole chunks
+// past the last gene without a bounds test.
+__host__ __device__ inline int64_t nb_tab_ld(int64_t G) { return (G + 12287) / 12288 * 12288; }
+
+__global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (g >= G) return;
+    if (g >= Gp) return;
+    if (g >= G) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            tab[(p * 3 + 0) * Gp + g] = 1.f;
+            tab[(p * 3 + 1) * Gp + g] = 0.f;
+            tab[(p * 3 + 2) * Gp + g] = 0.f;
+        }
+        return;
+    }
     const float t0 = theta[g * C + 0];
     const float t1 = C > 1 ? theta[g * C + 1] : 0.f;
 #pragma unroll
@@ -66,9 +82,9 @@ __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t 
         const float t = p == 0 ? t0 : (p == 1 ? t1 : t0 + t1);
         const float th = expf(t);
         const float lte = logf(th + 1e-8f);
-        tab[(p * 3 + 0) * G + g] = th;
-        tab[(p * 3 + 1) * G + g] = th * lte - lgamma_pos(th);
-        tab[(p * 3 + 2) * G + g] = lte + th / (th + 1e-8f) - digamma_pos(th);
+        tab[(p * 3 + 0) * Gp + g] = th;
+        tab[(p * 3 + 1) * Gp + g] = th * lte - lgamma_pos(th);
+        tab[(p * 3 + 2) * Gp + g] = lte + th / (th + 1e-8f) - digamma_pos(th);
     }
 }
 
@@ -242,9 +258,9 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
         const float* xrow = a.x + srow * a.ldx;
         const uint8_t* grow = a.goodloc + srow * a.ldg;
         const float sf = a.sizefactor[row];
-        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
-        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
-        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * nb_tab_ld(G);
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * nb_tab_ld(G);
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * nb_tab_ld(G);
         const float scale = -a.inv_B;
         // pass 1
         float mx = -INFINITY;
@@ -334,16 +350,57 @@ __global__ __launch_bounds__(NT) void nb_fwd_bwd_kernel(NbArgs a) {
     }
 }
 
-// Fast path (16-byte aligned rows, G % 4 == 0): the row's logits, counts and mask live in registers, every load of
-// a pass is in flight at once, and while chunk i of pass 4 is being evaluated the NEXT row's chunk i is already
-// being fetched into the registers chunk i has just released -- HBM latency hides under the log-likelihood maths.
+// ---- two-wide arithmetic for the fast NB kernel ---------------------------------------------------------------
+// The kernel is VALU-bound, so its per-gene arithmetic is written on pairs of genes: gfx950 issues v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 on two fp32 values at the price of one.  Transcendentals stay one per value.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 v2(float s) { return f32x2{s, s}; }
+__device__ __forceinline__ f32x2 vlog(f32x2 v) {  // natural log, arguments normal positive floats
+    return f32x2{__builtin_amdgcn_logf(v[0]), __builtin_amdgcn_logf(v[1])} * v2(0.6931471805599453f);
+}
+__device__ __forceinline__ f32x2 vrcp(f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
+
+// lgamma(z) and digamma(z), z > 0, by ONE upward shift of three taken unconditionally (no selects):
+//   lgamma(z) = lgamma(z+3) - log P,  digamma(z) = digamma(z+3) - P'/P,  P = z (z+1) (z+2)  (products, no cancellation)
+// and the asymptotic series at z+3 >= 3, three terms each: truncation lgamma < 1/(1680 * 3^7) = 2.7e-7,
+// digamma < 1/(240 * 3^8) = 6.4e-7 (absolute).  Four transcendentals per value: rcp, log of z+3; log, rcp of P.
+__device__ __forceinline__ void lgam_digam2(f32x2 z, f32x2& lg, f32x2& dg) {
+    const f32x2 z1 = z + v2(1.f), z2 = z + v2(2.f), zs = z + v2(3.f);
+    const f32x2 m12 = z1 * z2;
+    const f32x2 P = z * m12;
+    const f32x2 dP = z * (z1 + z2) + m12;
+    const f32x2 r = vrcp(zs), lz = vlog(zs);
+    const f32x2 r2 = r * r;
+    lg = (zs - v2(0.5f)) * lz - zs + v2(0.918938533205f) +
+         r * (v2(0.083333333333f) + r2 * (v2(-0.002777777778f) + r2 * v2(0.000793650794f))) - vlog(P);
+    dg = lz - v2(0.5f) * r - r2 * (v2(0.083333333333f) - r2 * (v2(0.008333333333f) - r2 * v2(0.003968253968f))) -
+         dP * vrcp(P);
+}
+
+// Fast path (16-byte aligned rows, G % 4 == 0): one workgroup walks whole rows; thread t owns columns
+// 4(t + NT i) .. +3 of chunk i.  Register plan (the row's state is held twice: this row's and the next row's):
+//   ev  the row's logits, then exp(logit - max): alive from the softmax statistics to pass B            4 NV
+//   nx  the NEXT row's logits, requested at the top of pass A: the statistics open a row, so this is the one fetch
+//       nothing else could hide (requested when pass B releases ev, it cost ~3 us of a ~20 us row)          4 NV
+//   xq / mq  counts and mask, three rolling slots: chunk i + 2 (or the next row's first chunks) is requested when
+//       chunk i is taken up                                                                                   15
+//   tq  theta, K1, K2 of the gene pair in hand and of the next one (L2-resident table)                        12
+//   p * dloss/dp waits for pass B in a second LDS row (thread-private addresses: no barrier)               LDS
+// 8 NV + 27 + ~55 temporaries: 768 threads x 7 chunks at 19k genes (three waves per SIMD, 168 registers).
+//   softmax statistics (max, sum of exp) over ev;
+//   pass A: everything per gene -- log-likelihood, d(theta) into the LDS accumulator, p * dloss/dp and its row sum S;
+//   pass B: dlogits = p * dloss/dp - p * S, stored once.
+// Nothing is recomputed between the passes.  Needs accumulator + the second row in the CU's 160 KB (G <= 20 448).
 template <typename TD, int NT, int NV, bool HAS_LGX>
 __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
+    static_assert(NV >= 2, "the rolling prefetch of counts reaches two chunks ahead");
     extern __shared__ __attribute__((aligned(16))) float dacc[];
     __shared__ float red[32];
     const int tid = threadIdx.x;
     const int64_t G = a.G;
-    const float eps = 1e-8f;
+    const int Gi = (int)G;
+    const int G4 = (Gi + 3) & ~3;
+    float* pgl = dacc + G4;  // [G4] floats: p * dloss/dp of the row in flight
     for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
     int cur_pat = -1, flushed = 0;
     float loss_acc = 0.f;
@@ -358,22 +415,34 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         flushed |= 1 << pat;
         __syncthreads();
     };
-    f32x4 ev[NV], xv[NV], pg[NV];
-    unsigned mb[NV];
+    f32x4 ev[NV], nx[NV];
+    f32x4 xq[3];       // counts of chunks i, i+1, i+2 (slot = chunk % 3)
+    unsigned mq[3];    // their masks
+    f32x2 tq[2][3];    // theta, K1, K2 of this gene pair and of the next one (slot = pair % 2)
     const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](int i, int64_t row) {
-        const int64_t c = 4ll * (tid + NT * i);
-        if (c < G) {
-            const int64_t srow = a.ridx ? a.ridx[row] : row;
-            ev[i] = *reinterpret_cast<const f32x4*>(a.logits + row * a.ldl + c);
-            xv[i] = *reinterpret_cast<const f32x4*>(a.x + srow * a.ldx + c);
-            mb[i] = *reinterpret_cast<const unsigned*>(a.goodloc + srow * a.ldg + c);
-        } else {
-            ev[i] = ninf; xv[i] = zero4; mb[i] = 0u;
-        }
+    // Rows are addressed through buffer resources (base = the row, extent = its G elements): every lane of every wave
+    // issues every memory operation of every chunk -- a lane past the last gene loads zeros and its store is dropped
+    // by the bounds check -- so control flow is uniform and ONE per-lane offset register (16 * tid, shifted for the
+    // 1- and 2-byte rows) serves all chunks: the chunk offset is an instruction constant.
+    constexpr unsigned kRsrcFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9)
+    auto row_rsrc = [&](const void* base, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+    };
+    const int v16 = tid * 16;
+    auto load_o = [&](int i, __amdgpu_buffer_rsrc_t r) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v16, i * NT * 16, 0));
+    };
+    auto load_x = [&](int i, __amdgpu_buffer_rsrc_t rx) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, v16, i * NT * 16, 0));
+    };
+    auto load_m = [&](int i, __amdgpu_buffer_rsrc_t rg) {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, tid * 4, i * NT * 4, 0);
     };
     int64_t pref_row = -1;
+    // `4 * (tid + NT * i) < always`: true for every lane and chunk, but not to the compiler (it does not know G >= 0): a
+    // real branch around each chunk's (and each gene pair's) body keeps its temporaries and loads from being
+    // interleaved with the others' (as straight-line code the register allocator spilled 300 registers)
+    const int always = Gi + 4 * NT * NV + 8;
     for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
         int has0 = 0, has1 = 0, bad = 0;
         for (int j = 0; j < a.C; ++j) {
@@ -392,18 +461,44 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             cur_pat = pat;
         }
         if (pref_row != row) {
+            const int64_t srow = a.ridx ? a.ridx[row] : row;
+            const auto rx = row_rsrc(a.x + srow * a.ldx, Gi * 4);
+            const auto rg = row_rsrc(a.goodloc + srow * a.ldg, Gi);
+            const auto rl = row_rsrc(a.logits + row * a.ldl, Gi * 4);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) fetch(i, row);
+            for (int i = 0; i < NV; ++i) ev[i] = load_o(i, rl);
+#pragma unroll
+            for (int i = 0; i < 2 && i < NV; ++i) { xq[i] = load_x(i, rx); mq[i] = load_m(i, rg); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) ev[i] = nx[i];
+            // the previous row's last two chunks requested this row's chunks 0 and 1 into the slots they had free
+            // (chunk NV + k lands in slot (NV + k) % 3): rotate them to slots 0 and 1
+            if (NV % 3 == 1) { const f32x4 t = xq[1]; const unsigned u = mq[1]; xq[1] = xq[2]; mq[1] = mq[2]; xq[0] = t; mq[0] = u; }
+            if (NV % 3 == 2) { const f32x4 t = xq[2]; const unsigned u = mq[2]; xq[1] = xq[0]; mq[1] = mq[0]; xq[0] = t; mq[0] = u; }
         }
+        const int64_t srow_c = a.ridx ? a.ridx[row] : row;
+        const auto rxc = row_rsrc(a.x + srow_c * a.ldx, Gi * 4);
+        const auto rgc = row_rsrc(a.goodloc + srow_c * a.ldg, Gi);
+        const int64_t nrow = row + gridDim.x;  // next row of this workgroup (for the prefetch)
+        const bool has_next = nrow < a.B;
+        const int64_t nsrow = has_next ? (a.ridx ? a.ridx[nrow] : nrow) : 0;
+        const auto nrl = row_rsrc(a.logits + (has_next ? nrow : row) * a.ldl, Gi * 4);
+        const auto nrx = row_rsrc(a.x + nsrow * a.ldx, Gi * 4);
+        const auto nrg = row_rsrc(a.goodloc + nsrow * a.ldg, Gi);
         const float sf = a.sizefactor[row];
-        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
-        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
-        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float lgx_row = HAS_LGX ? a.lgx[row] : 0.f;
+        const int64_t Gp = nb_tab_ld(G);
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * Gp + 4 * tid;
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * Gp + 4 * tid;
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * Gp + 4 * tid;
         const float scale = -a.inv_B;
-        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
+        for (int i = 0; i < NV; ++i) {
+            if (4 * (tid + NT * i) >= Gi) ev[i] = ninf;  // columns past the end: exp(-inf - max) = 0
+            mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
+        }
         mx = block_max<NT>(mx, red);
         float sm = 0.f;
 #pragma unroll
@@ -415,67 +510,97 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             }
         sm = block_sum<NT>(sm, red);
         const float inv_sum = 1.0f / sm;
-        float S = 0.f;
+        const f32x2 cmu = v2(sf * inv_sum), eps2 = v2(1e-8f);
+        if (has_next) {  // a whole row of arithmetic lies ahead: request the next row's logits now
+#pragma unroll
+            for (int i = 0; i < NV; ++i) nx[i] = load_o(i, nrl);
+        }
+        // ---- pass A
+        f32x2 S2 = v2(0.f), L2 = v2(0.f);
+        // (padded table: always in bounds; 8 bytes per lane and load, L2-resident, requested one gene pair ahead)
+        auto load_tab = [&](int pair, f32x2 (&t)[3]) {
+            t[0] = *reinterpret_cast<const f32x2*>(tth + 4 * NT * (pair >> 1) + 2 * (pair & 1));
+            t[1] = *reinterpret_cast<const f32x2*>(tk1 + 4 * NT * (pair >> 1) + 2 * (pair & 1));
+            t[2] = *reinterpret_cast<const f32x2*>(tk2 + 4 * NT * (pair >> 1) + 2 * (pair & 1));
+        };
+        load_tab(0, tq[0]);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int64_t c = 4ll * (tid + NT * i);
-            const f32x4 t0 = c < G ? *reinterpret_cast<const f32x4*>(tth + c) : one4;
+            // this chunk's counts and mask were requested two chunks ago; request those of chunk i + 2 (of the next row
+            // when this row ends) into the slot chunk i - 1 has released
+            const f32x4 xcur = xq[i % 3];
+            const unsigned mcur = mq[i % 3];
+            if (i + 2 < NV) { xq[(i + 2) % 3] = load_x(i + 2, rxc); mq[(i + 2) % 3] = load_m(i + 2, rgc); }
+            else if (has_next) { xq[(i + 2) % 3] = load_x(i + 2 - NV, nrx); mq[(i + 2) % 3] = load_m(i + 2 - NV, nrg); }
+            if (4 * (tid + NT * i) < Gi) {  // (waves wholly past the last gene skip the chunk)
+                f32x4 dt4, pg4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float mu = sf * ev[i][k] * inv_sum;
-                const float zt = xv[i][k] + t0[k];
-                const float v = xv[i][k] * mu * frcp(mu + eps) - zt * mu * frcp(t0[k] + mu + eps);
-                pg[i][k] = ((mb[i] >> (8 * k)) & 0xffu) ? scale * v : 0.f;  // p * dloss/dp, kept for pass 4
-                S += pg[i][k];
+                for (int h = 0; h < 2; ++h) if (4 * (tid + NT * i) + 2 * h < always) {  // (its own basic block, as above)
+                    if (2 * i + h + 1 < 2 * NV) load_tab(2 * i + h + 1, tq[(h + 1) & 1]);
+                    // keep-mask of the two genes as 0/1 floats (0 past the last gene: the mask load returned zeros); a
+                    // count under a cleared mask may hold anything (the reference zeroes ll there after the fact): it is
+                    // replaced by 0 so that everything below is finite
+                    const float b0 = (float)((mcur >> (16 * h)) & 0xffu), b1 = (float)((mcur >> (16 * h + 8)) & 0xffu);
+                    const f32x2 mf = f32x2{b0 != 0.f ? 1.f : 0.f, b1 != 0.f ? 1.f : 0.f};
+                    const f32x2 x = f32x2{b0 != 0.f ? xcur[2 * h] : 0.f, b1 != 0.f ? xcur[2 * h + 1] : 0.f};
+                    const f32x2 e = f32x2{ev[i][2 * h], ev[i][2 * h + 1]};
+                    const f32x2 th = tq[h][0], k1 = tq[h][1], k2 = tq[h][2];  // (pair 2i + h: slot h)
+                    const f32x2 mu = e * cmu;
+                    const f32x2 mue = mu + eps2;
+                    const f32x2 tm = th + mue;
+                    const f32x2 rtm = vrcp(tm), ltm = vlog(tm);
+                    const f32x2 rme = vrcp(mue), lme = vlog(mue);
+                    const f32x2 zt = x + th;
+                    f32x2 lg, dg;
+                    lgam_digam2(zt, lg, dg);
+                    // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
+                    f32x2 ll = k1 - zt * ltm + x * lme + lg;
+                    if (!HAS_LGX) ll -= f32x2{lgamma_fast(x[0] + 1.0f), lgamma_fast(x[1] + 1.0f)};
+                    // mu * dll/dmu = x mu/(mu+eps) - (theta+x) mu/(theta+mu+eps)
+                    const f32x2 dmu_mu = x * (mu * rme) - zt * (mu * rtm);
+                    // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
+                    const f32x2 dth = k2 - ltm - zt * rtm + dg;
+                    const f32x2 smf = mf * v2(scale);
+                    const f32x2 pgh = smf * dmu_mu;  // p * dloss/dp
+                    const f32x2 dth2 = smf * (th * dth);
+                    pg4[2 * h] = pgh[0]; pg4[2 * h + 1] = pgh[1];
+                    dt4[2 * h] = dth2[0]; dt4[2 * h + 1] = dth2[1];
+                    S2 += pgh;
+                    L2 += mf * ll;
+                }
+                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i));
+                acc += dt4;
+                *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = acc;
+                *reinterpret_cast<f32x4*>(pgl + 4 * (tid + NT * i)) = pg4;
             }
         }
-        S = block_sum<NT>(S, red);
-        // next row of this workgroup (for the prefetch)
-        const int64_t nrow = row + gridDim.x;
-        TD* drow = reinterpret_cast<TD*>(a.dlogits) + row * a.lddl;
+        loss_acc += L2[0] + L2[1];
+        const float S = block_sum<NT>(S2[0] + S2[1], red);
+        // ---- pass B
+        const float cS = inv_sum * S;
+        const auto rd = row_rsrc(reinterpret_cast<TD*>(a.dlogits) + row * a.lddl, Gi * (int)sizeof(TD));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int64_t c0 = 4ll * (tid + NT * i);
-            if (c0 < G) {
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tth + c0);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tk1 + c0);
-                const f32x4 t2 = *reinterpret_cast<const f32x4*>(tk2 + c0);
-                float d[4], dt[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool m = (mb[i] >> (8 * k)) & 0xffu;
-                    const float p = ev[i][k] * inv_sum;
-                    const float mu = sf * p;
-                    const float th = t0[k], x = xv[i][k];
-                    const float tm = th + mu + eps;
-                    const float ltm = flog(tm);
-                    const float zt = x + th;
-                    float lg, dg;
-                    lgam_digam_fast(zt, lg, dg);
-                    float ll = t1[k] - zt * ltm + x * flog(mu + eps) + lg;
-                    if (!HAS_LGX) ll -= lgamma_fast(x + 1.0f);
-                    const float dth = t2[k] - ltm - zt * frcp(tm) + dg;
-                    d[k] = pg[i][k] - p * S;
-                    dt[k] = m ? scale * th * dth : 0.f;
-                    loss_acc += m ? ll : 0.f;
-                }
-                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c0);
-                acc[0] += dt[0]; acc[1] += dt[1]; acc[2] += dt[2]; acc[3] += dt[3];
-                *reinterpret_cast<f32x4*>(dacc + c0) = acc;
-                if (sizeof(TD) == 4) {
-                    f32x4 o = {d[0], d[1], d[2], d[3]};
-                    *reinterpret_cast<f32x4*>(drow + c0) = o;
-                } else {
-                    u32x2 pk;
-                    pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
-                    pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
-                    *reinterpret_cast<u32x2*>(drow + c0) = pk;
-                }
+            f32x4 pg4 = {0.f, 0.f, 0.f, 0.f};
+            if (4 * (tid + NT * i) < Gi) pg4 = *reinterpret_cast<const f32x4*>(pgl + 4 * (tid + NT * i));
+            const f32x4 d = pg4 - ev[i] * cS;
+            if (sizeof(TD) == 4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rd, v16, i * NT * 16, 0);
+                // Observed on gfx950 (ROCm 7.2): a VALU write of this store's first data register in the very next issue
+                // slot reached memory instead of the value stored (zeros in component 0 of lanes 12-15 of each 16, varying
+                // from run to run).  hipcc sees no hazard for a buffer store whose soffset is a scalar register; with one
+                // instruction in between the stores were always right.  Two idle issue slots, nothing moved across them:
+                asm volatile("s_nop 1" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                u32x2 pk;
+                pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
+                pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rd, tid * 8, i * NT * 8, 0);
             }
-            if (nrow < a.B) fetch(i, nrow);  // registers of chunk i are free: start the next row's loads
         }
-        if (HAS_LGX && tid == 0) loss_acc -= a.lgx[row];
-        pref_row = nrow < a.B ? nrow : -1;
+        if (HAS_LGX && tid == 0) loss_acc -= lgx_row;
+        pref_row = has_next ? nrow : -1;
     }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
@@ -594,9 +719,9 @@ __global__ __launch_bounds__(NT) void zinb_fwd_bwd_kernel(NbArgs a, ZinbExtra z)
         const float* xrow = a.x + srow * a.ldx;
         const uint8_t* grow = a.goodloc + srow * a.ldg;
         const float sf = a.sizefactor[row];
-        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * G;
-        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * G;
-        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * G;
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * nb_tab_ld(G);
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * nb_tab_ld(G);
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * nb_tab_ld(G);
         const float scale = -a.inv_B;
         float mx = -INFINITY;
         for (int64_t c = tid; c < G; c += NT) mx = fmaxf(mx, orow[c]);
@@ -739,7 +864,7 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     (void)C;
     const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
     // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
-    return (size_t)(9 * G + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G);
+    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G);
 }
 
 template <typename TD>
@@ -760,24 +885,27 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     do {                                                                                                      \
         auto kf = nb_rowreg_kernel<TD, NT, NV, false>;                                                         \
         auto kl = nb_rowreg_kernel<TD, NT, NV, true>;                                                          \
-        if (lds > 48 * 1024) {                                                                                \
-            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        const size_t l = 2 * lds; /* the accumulator and the row of p * dloss/dp */                            \
+        if (l > 48 * 1024) {                                                                                  \
+            (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
+            (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
         }                                                                                                     \
-        if (a.lgx) hipLaunchKernelGGL(kl, dim3(ngroups), dim3(NT), lds, st, a);                                \
-        else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), lds, st, a);                                      \
+        if (a.lgx) hipLaunchKernelGGL(kl, dim3(ngroups), dim3(NT), l, st, a);                                  \
+        else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), l, st, a);                                        \
         return 0;                                                                                             \
     } while (0)
-    if (vec) {
+    if (vec && 2 * lds + 256 <= 160 * 1024) {  // two LDS rows fit the CU (G <= 20 448)
         const int64_t G = a.G;
-        if (G <= 1024) NB_F(256, 1);
+        if (G <= 1024) NB_F(128, 2);  // (the rolling prefetch needs at least two chunks)
         if (G <= 2048) NB_F(256, 2);
         if (G <= 4096) NB_F(256, 4);
         if (G <= 8192) NB_F(1024, 2);
         if (G <= 12288) NB_F(1024, 3);
-        if (G <= 16384) NB_F(1024, 4);
-        if (G <= 20480) NB_F(1024, 5);
-        if (G <= 24576) NB_F(1024, 6);
+        if (G <= 15360) NB_F(768, 5);
+        if (G <= 18432) NB_F(768, 6);
+        // (measured at 4096 x 19000: 768 x 7 320 us; 1024 x 5, four waves per SIMD but 128 registers and 22 of them spilled,
+        // 411 us)
+        if (G <= 20448) NB_F(768, 7);
     }
     if (a.G <= 4096) NB_L(256);
     else NB_L(1024);
@@ -802,10 +930,10 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
     float* tab = ws;
-    float* part_dt = tab + 9 * G;
+    float* part_dt = tab + 9 * nb_tab_ld(G);
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
-    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
@@ -838,10 +966,10 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
     float* tab = ws;
-    float* part_dt = tab + 9 * G;
+    float* part_dt = tab + 9 * nb_tab_ld(G);
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
-    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, theta, C, G, tab);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     ZinbExtra z{pi, dpi, ldpi, lddpi};
