@@ -218,7 +218,8 @@ def main():
 
     def step(src):
         b = next(src)
-        rows_done[0] += int(b["sizefactor"].numel())  # rows this rank really processed (host-side shape, no sync)
+        # rows this rank really processed (host-side shape, no sync); a captured step's batch carries its row count
+        rows_done[0] += int(b.n) if hasattr(b, "n") else int(b["sizefactor"].numel())
         trainer.on_iteration(b)
 
     def sync():
@@ -260,7 +261,9 @@ def main():
         trace(f"warmup step {i} launched")
     sync()
     trace("warmup done")
-    ops.PROFILE_GEMM = []  # (flops, start_event, end_event) of every gene-width GEMM launch in the timed region
+    # (flops, start_event, end_event) of every gene-width GEMM launch in the timed region.  A replayed graph cannot carry
+    # the events: with --graph the same K steps are timed once more further down, launched the ordinary way, for them.
+    ops.PROFILE_GEMM = None if use_graph else []
     prof_host = None
     if os.environ.get("C2_BENCH_CPROFILE"):  # developer aid: cProfile of the host launch path of the timed steps
         import cProfile
@@ -272,6 +275,7 @@ def main():
         prof_host.disable()
         pstats.Stats(prof_host, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+    losses_seen = [float(trainer.current_loss)]
     trace("timed steps done")
     model._engine().check_status()
     dt, cells = over_ranks(dt, rows)
@@ -288,12 +292,19 @@ def main():
     # Third, untuned-pipeline timing of the same K steps: every data-only term is evaluated INSIDE the step, as the
     # reference's forward does (log(1+x) of the batch, lgamma(x+1) of the NB likelihood; the batch's counts and mask
     # copied by the gather) instead of once per resident dataset.  Reported beside the headline value.
+    if use_graph:
+        trainer.drop_graph()
+        trainer.graph = trainer.dataloader_train.static = False
+        eager = batches()
+        for _ in range(2):
+            step(eager)
+        ops.PROFILE_GEMM = []
+        timed(args.steps, eager)
+        prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
     all_in_step = None
     if world == 1:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
         ld = trainer.dataloader_train
         ld.nb_const, ld.resident_xin = False, (lambda n: False)
-        if hasattr(trainer, "drop_graph"):
-            trainer.drop_graph()
         stream2 = batches()
         for _ in range(2):
             step(stream2)
@@ -303,7 +314,7 @@ def main():
     if os.environ.get("C2_BENCH_TRACE"):
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
-    last = [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
+    last = losses_seen + [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
     assert all(np.isfinite(last)), f"non-finite losses {last}"
     n_gpus = dist.get_world_size() if world > 1 else 1
 
@@ -340,6 +351,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": "c2::wide::gemm_wide_kernel<*,*,8> (gene-width Linear fwd/dgrad/wgrad)",
+                         "timed_in": "the K timed steps" if not use_graph else "the same K steps launched without the graph",
                          "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
                          "gemm_ms_per_step": gemm_ms / args.steps, "gemm_flops_per_step": gemm_flops / args.steps,
                          "gemm_flops_per_step_expected": 5 * 2.0 * B * cfg["G"] * H1},

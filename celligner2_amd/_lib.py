@@ -24,6 +24,11 @@ lib = C.CDLL(LIB_PATH)
 i64, i32, f32, f64, vp, sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
 
+class AdamState(C.Structure):
+    _fields_ = [("step", i64), ("lr", f64), ("beta1", f64), ("beta2", f64), ("eps", f64), ("weight_decay", f64),
+                ("clip_value", f64)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp)]
 
@@ -68,6 +73,12 @@ _SIGS = {
     "c2_mmd_static_floats": (sz, []),
     "c2_mmd_fwd_bwd_static": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i64, f32, vp, vp, i64, vp]),
     "c2_adam_step": (i32, [C.POINTER(AdamTensor), i32, f64, f64, f64, f64, f64, f64, i64, vp]),
+    "c2_adam_hyper_bytes": (sz, []),
+    "c2_adam_prepare": (i32, [vp, vp, vp]),
+    "c2_adam_step_dev": (i32, [C.POINTER(AdamTensor), i32, vp, vp]),
+    "c2_combine_losses_dev": (i32, [vp, vp, vp, vp, vp]),
+    "c2_scale4_dev": (i32, [vp, vp, vp, vp]),
+    "c2_dropout_masks_dev": (i32, [vp, i64, f32, C.c_uint64, vp, C.c_uint64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
                              vp, i64, vp]),

@@ -28,7 +28,32 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - h.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
+// Step state on the device (c2_adam_state of c2mi.h): one thread advances the step count and turns the hyper-parameters
+// into the kernel's fp32 constants exactly as the host does for c2_adam_step (double arithmetic, rounded once).
+__global__ void adam_prepare_kernel(c2_adam_state* st, AdamHyper* h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->step += 1;
+    const double bc1 = 1.0 - pow(st->beta1, (double)st->step);
+    const double bc2 = 1.0 - pow(st->beta2, (double)st->step);
+    h->step_size = (float)(st->lr / bc1);
+    h->beta1 = (float)st->beta1; h->beta2 = (float)st->beta2;
+    h->omb1 = (float)(1.0 - st->beta1); h->omb2 = (float)(1.0 - st->beta2);
+    h->eps = (float)st->eps; h->wd = (float)st->weight_decay; h->clip = (float)st->clip_value;
+    h->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h);
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamTable tab, const AdamHyper* hp);
+
+__device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper& h);
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) { adam_block(tab, h); }
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamTable tab, const AdamHyper* hp) {
+    const AdamHyper h = *hp;  // (uniform address: scalar loads)
+    adam_block(tab, h);
+}
+
+__device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper& h) {
     // locate the tensor of this block (tab.n <= 48: linear scan on scalar registers)
     int ti = 0;
     while (ti + 1 < tab.n && (int)blockIdx.x >= tab.first_block[ti + 1]) ++ti;
@@ -90,18 +115,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable tab, AdamHyper h) {
 
 using namespace c2;
 
-extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2,
-                            double eps, double weight_decay, double clip_value, int64_t step_t, void* stream) {
-    C2_CHECK(desc_host || n_tensors == 0, "null descriptor table");
-    C2_CHECK(step_t >= 1, "step_t must be >= 1");
-    const double bc1 = 1.0 - pow(beta1, (double)step_t);
-    const double bc2 = 1.0 - pow(beta2, (double)step_t);
-    AdamHyper h;
-    h.step_size = (float)(lr / bc1);
-    h.beta1 = (float)beta1; h.beta2 = (float)beta2;
-    h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);  // as torch: 1-beta in double
-    h.eps = (float)eps; h.wd = (float)weight_decay; h.clip = (float)clip_value;
-    h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+// hp_dev == NULL: hyper-parameters by value (h); else read from device memory by every block
+static int adam_launch(const c2_adam_tensor* desc_host, int n_tensors, const AdamHyper& h, const AdamHyper* hp_dev,
+                       void* stream) {
     for (int i = 0; i < n_tensors;) {  // one launch per kMaxT NON-EMPTY descriptors; i = descriptors consumed so far
         AdamTable tab;
         tab.n = 0;
@@ -118,8 +134,40 @@ extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, doub
         }
         tab.first_block[tab.n] = blocks;
         if (blocks == 0) continue;
-        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, h);
+        if (hp_dev) hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, hp_dev);
+        else hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tab, h);
     }
     C2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2,
+                            double eps, double weight_decay, double clip_value, int64_t step_t, void* stream) {
+    C2_CHECK(desc_host || n_tensors == 0, "null descriptor table");
+    C2_CHECK(step_t >= 1, "step_t must be >= 1");
+    const double bc1 = 1.0 - pow(beta1, (double)step_t);
+    const double bc2 = 1.0 - pow(beta2, (double)step_t);
+    AdamHyper h;
+    h.step_size = (float)(lr / bc1);
+    h.beta1 = (float)beta1; h.beta2 = (float)beta2;
+    h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);  // as torch: 1-beta in double
+    h.eps = (float)eps; h.wd = (float)weight_decay; h.clip = (float)clip_value;
+    h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    return adam_launch(desc_host, n_tensors, h, nullptr, stream);
+}
+
+extern "C" size_t c2_adam_hyper_bytes(void) { return sizeof(AdamHyper); }
+
+extern "C" int c2_adam_prepare(c2_adam_state* state_dev, void* hyper_dev, void* stream) {
+    C2_CHECK(state_dev && hyper_dev, "null pointer");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (AdamHyper*)hyper_dev);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_adam_step_dev(const c2_adam_tensor* desc_host, int n_tensors, const void* hyper_dev, void* stream) {
+    C2_CHECK(desc_host || n_tensors == 0, "null descriptor table");
+    C2_CHECK(hyper_dev, "null hyper-parameter block");
+    AdamHyper unused{};
+    return adam_launch(desc_host, n_tensors, unused, (const AdamHyper*)hyper_dev, stream);
 }

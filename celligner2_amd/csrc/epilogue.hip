@@ -754,6 +754,53 @@ __global__ void scale4_kernel(const float* __restrict__ g, float w0, float w1, f
         out[0] = w0 * s; out[1] = w1 * s; out[2] = w2 * s; out[3] = w3 * s;
     }
 }
+// The same two with the four weights read from device memory (a step replayed as a HIP graph bakes every by-value
+// argument in: the KL weight changes per epoch, so it has to live on the device); accum6 (may be NULL) += out6, the
+// running sums an epoch's mean losses are made of without a host read per step.
+__global__ void combine_losses_dev_kernel(const float* __restrict__ l, const float* __restrict__ w,
+                                          float* __restrict__ out, double* __restrict__ accum) {
+    if (threadIdx.x == 0) {
+        const float a = l[0], b = l[1], c = l[2], d = l[3];
+        const float t = ((w[0] * a + w[1] * b) + w[2] * c) + w[3] * d, u = (a + b) + c;
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = t; out[5] = u;
+        if (accum) {
+            accum[0] += a; accum[1] += b; accum[2] += c; accum[3] += d; accum[4] += t; accum[5] += u;
+        }
+    }
+}
+__global__ void scale4_dev_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out) {
+    if (threadIdx.x < 4) out[threadIdx.x] = w[threadIdx.x] * (g ? g[0] : 1.f);
+}
+// Dropout masks with the Philox counter offset in device memory; a second one-thread launch advances it after every
+// block of the mask kernel has read it (stream order).
+__global__ void dropout_mask_dev_kernel(uint8_t* __restrict__ out, int64_t n, unsigned thresh8, unsigned long long seed,
+                                        const unsigned long long* __restrict__ offset_dev) {
+    const unsigned long long offset = *offset_dev;
+    const int64_t nvec = (n + 15) / 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned r[4];
+        const unsigned long long ctr = offset + (unsigned long long)i;
+        philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0x3c6ef372u, 0xdaa66d2bu, (unsigned)seed,
+                      (unsigned)(seed >> 32), r);
+        u32x4 pk;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (((r[w] >> (8 * b)) & 0xffu) >= thresh8 ? 1u : 0u) << (8 * b);
+            pk[w] = v;
+        }
+        if ((i + 1) * 16 <= n) {
+            *reinterpret_cast<u32x4*>(out + i * 16) = pk;
+        } else {
+            for (int64_t b = i * 16; b < n; ++b) out[b] = (uint8_t)((pk[(b & 15) >> 2] >> (8 * (b & 3))) & 0xffu);
+        }
+    }
+}
+__global__ void advance_counter_kernel(unsigned long long* ctr, unsigned long long by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += by;
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, const float* __restrict__ a_dev, float* __restrict__ y,
                              int64_t n) {
     const float a = *a_dev;
@@ -1053,6 +1100,36 @@ extern "C" int c2_combine_losses(const float* losses4, float w0, float w1, float
 extern "C" int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float* out4, void* stream) {
     C2_CHECK(out4, "null pointer");
     hipLaunchKernelGGL(scale4_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_dev, w0, w1, w2, w3, out4);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_combine_losses_dev(const float* losses4, const float* w_dev, float* out6, double* accum6,
+                                     void* stream) {
+    C2_CHECK(losses4 && w_dev && out6, "null pointer");
+    hipLaunchKernelGGL(combine_losses_dev_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses4, w_dev, out6, accum6);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* stream) {
+    C2_CHECK(w_dev && out4, "null pointer");
+    hipLaunchKernelGGL(scale4_dev_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_dev, w_dev, out4);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev,
+                                    uint64_t advance, void* stream) {
+    C2_CHECK(out && offset_dev && n >= 0 && aligned16(out), "out must be a 16-byte aligned buffer");
+    C2_CHECK(p_drop >= 0.f && p_drop < 1.f, "bad dropout rate");
+    if (n > 0) {
+        const unsigned thresh8 = (unsigned)lrintf(p_drop * 256.f);
+        hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, out, n,
+                           thresh8, (unsigned long long)seed, (const unsigned long long*)offset_dev);
+    }
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)offset_dev,
+                       (unsigned long long)advance);
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,8 @@ Precision modes
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import torch
 
 from . import ops
@@ -44,6 +46,8 @@ class StepEngine:
         self.x3 = precision == "bf16"  # narrow fp32-operand GEMMs run as 3 bf16 MFMA products in bf16 mode
         self.dev = next(iter(params.values())).device
         self._ws = {}
+        self._pool = {}       # key -> OrderedDict[(shape, dtype)] -> tensor, least recently used first (see buf)
+        self.recorded = None  # list while a step is being captured: every scratch tensor it uses
         self._shadow = {}
         self._shadow_ver = {}
         self._wplanes = {}   # bf16x3: (version, [2,N,K] bf16 planes) of the fp32 weights of the narrow layers
@@ -106,12 +110,28 @@ class StepEngine:
         return self.T if max(self.p[wname].shape) >= self.WIDE else F32
 
     # ------------------------------------------------------------------ buffers
+    KEEP_SHAPES = 4  # train / validation batches, each full-size and short
+
     def buf(self, key, shape, dtype=F32):
-        t = self._ws.get(key)
-        shape = tuple(int(s) for s in shape)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.dev)
-            self._ws[key] = t
+        """The scratch tensor `key` in this shape: self._ws[key] afterwards.  Every key keeps its KEEP_SHAPES most
+        recently used shapes, so alternating batch sizes (the short last batch of an epoch, validation) do not free and
+        re-allocate the workspace twice per epoch -- and a step captured as a HIP graph for one batch size keeps its
+        addresses while other sizes run.  While `self.recorded` is a list, every tensor handed out is appended to it (a
+        captured graph keeps that list: what it wrote to stays allocated even if the pool later lets go of it)."""
+        shapes = self._pool.get(key)
+        if shapes is None:
+            shapes = self._pool[key] = OrderedDict()
+        slot = (tuple(int(s) for s in shape), dtype)
+        t = shapes.get(slot)
+        if t is None:
+            t = shapes[slot] = torch.empty(slot[0], dtype=dtype, device=self.dev)
+            if len(shapes) > self.KEEP_SHAPES:
+                shapes.popitem(last=False)
+        else:
+            shapes.move_to_end(slot)
+        self._ws[key] = t
+        if self.recorded is not None:
+            self.recorded.append(t)
         return t
 
     def _readiness_order(self):

@@ -185,7 +185,10 @@ class _StepTotalFn(torch.autograd.Function):
         eng = model.__dict__["_eng"]  # validated by Celligner2.forward just before
         losses = eng.forward(batch, eps, masks, train=model.training, save=True)
         out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
-        ops.combine_losses(losses, weights, out6)
+        if torch.is_tensor(weights):  # device-resident weights (a step that is replayed as a HIP graph)
+            ops.combine_losses_dev(losses, weights, out6, model.__dict__.get("_loss_sums"))
+        else:
+            ops.combine_losses(losses, weights, out6)
         ctx.model, ctx.weights, ctx.gen = model, weights, eng.generation
         ctx.set_materialize_grads(False)  # no zero-fill launch for the loss vector's (absent) gradient
         total = out6[4]
@@ -196,7 +199,9 @@ class _StepTotalFn(torch.autograd.Function):
     def backward(ctx, gtotal, _g6):
         model = ctx.model
         eng = model.__dict__["_eng"]
-        g = ops.scale4(gtotal.float().contiguous() if gtotal is not None else None, ctx.weights, eng.buf("gseed", (4,)))
+        up = gtotal.float().contiguous() if gtotal is not None else None
+        scale4 = ops.scale4_dev if torch.is_tensor(ctx.weights) else ops.scale4
+        g = scale4(up, ctx.weights, eng.buf("gseed", (4,)))
         _keep_accumulated(model, eng)
         grads = eng.backward(g, gen=ctx.gen)
         return (None, None, None, None, None) + _hand_over(model, eng, grads)
@@ -420,15 +425,25 @@ class Celligner2(nn.Module):
                 # counter range of a step is cut into one stretch per rank
                 sizes = [(s[0] * s[1] + 15) // 16 * 16 for _, s in allshapes]
                 total = sum(sizes)
-                flat = self.__dict__.get("_mask_buf")
-                if flat is None or flat.numel() != total or flat.device != device:
-                    flat = torch.empty(total, dtype=torch.uint8, device=device)
-                    self.__dict__["_mask_buf"] = flat
+                # (one buffer per batch shape, ONE counter for all of them: a short last batch neither evicts the
+                # full-size buffer nor restarts the stream)
+                bufs = self.__dict__.setdefault("_mask_bufs", {})
+                flat = bufs.get((total, device))
+                if flat is None:
+                    flat = bufs[(total, device)] = torch.empty(total, dtype=torch.uint8, device=device)
+                if "_mask_seed" not in self.__dict__:
                     self.__dict__["_mask_seed"] = torch.initial_seed()
                     self.__dict__["_mask_offset"] = 0
-                ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"],
-                                  self.__dict__["_mask_offset"] + r * (total // 16))
-                self.__dict__["_mask_offset"] += W * (total // 16)
+                ctr = self.__dict__.get("_mask_counter")
+                if ctr is not None and W == 1:
+                    if ctr is False or ctr.device != device:
+                        ctr = self.__dict__["_mask_counter"] = torch.tensor(
+                            [self.__dict__["_mask_offset"]], dtype=torch.int64, device=device)
+                    ops.dropout_masks_dev(flat, self.dr_rate, self.__dict__["_mask_seed"], ctr, total // 16)
+                else:
+                    ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"],
+                                      self.__dict__["_mask_offset"] + r * (total // 16))
+                    self.__dict__["_mask_offset"] += W * (total // 16)
                 o = 0
                 for (n, s), sz in zip(allshapes, sizes):
                     masks[n] = flat[o:o + s[0] * s[1]].view(s)
@@ -492,7 +507,11 @@ class Celligner2(nn.Module):
         eng = self._engine()
         if weights is not None:
             out6 = torch.empty(6, dtype=torch.float32, device=dev)
-            ops.combine_losses(eng.forward(bt, eps, masks, train=self.training, save=False), weights, out6)
+            losses = eng.forward(bt, eps, masks, train=self.training, save=False)
+            if torch.is_tensor(weights):
+                ops.combine_losses_dev(losses, weights, out6)
+            else:
+                ops.combine_losses(losses, weights, out6)
             return out6[4], out6
         losses = eng.forward(bt, eps, masks, train=self.training, save=False).clone()
         return losses[0], losses[1], losses[2], losses[3]
@@ -502,11 +521,36 @@ class Celligner2(nn.Module):
         (differentiable) and v = [recon, kl, mmd, ce, total, recon+kl+mmd] (fp32 [6], no gradient).  What the
         trainer's `loss = recon + alpha*kl + mmd + ce` (semisupervised.py:63-66) needs, without the dozen
         single-element torch kernels that expression and its autograd graph launch."""
-        self.__dict__["_total_weights"] = tuple(float(w) for w in weights)
+        if torch.is_tensor(weights):
+            # fp32 [4] on the device, read by the kernels when they run: the form a captured step needs (its KL weight
+            # changes between replays); `loss_sums(...)` registers the float64 [6] running sums of v
+            self.__dict__["_total_weights"] = weights
+        else:
+            self.__dict__["_total_weights"] = tuple(float(w) for w in weights)
         try:
             return self(**batch)
         finally:
             self.__dict__.pop("_total_weights", None)
+
+    def loss_sums(self, sums):
+        """Register (or, with None, remove) a float64 [6] device tensor to which every training forward_total with
+        device-resident weights adds its loss vector: an epoch's mean losses without a host read per step."""
+        if sums is None:
+            self.__dict__.pop("_loss_sums", None)
+        else:
+            assert sums.is_cuda and sums.dtype == torch.float64 and sums.numel() == 6
+            self.__dict__["_loss_sums"] = sums
+
+    def device_noise_counter(self, on):
+        """rng_mode "device": keep the dropout masks' Philox counter in device memory (advanced by the mask launch
+        itself), so that a replayed step draws fresh masks.  Switching back reads it (one sync).  Same masks either
+        way: only where the counter lives changes."""
+        if on and self.__dict__.get("_mask_counter") is None:
+            self.__dict__["_mask_counter"] = False  # created by the first draw, from the host's count
+        elif not on and self.__dict__.get("_mask_counter") is not None:
+            c = self.__dict__.pop("_mask_counter")
+            if c is not False:
+                self.__dict__["_mask_offset"] = int(c.item())
 
     def sampling(self, mu, log_var):
         """othermodels/base/_base.py:464-480."""

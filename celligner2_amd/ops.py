@@ -480,6 +480,12 @@ def mmd_static(feat, part_id, wt, row0, Bl, beta, loss_out, dfeat):
 def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
     """entries: list of (p, g, m, v, shadow_or_None) contiguous fp32 tensors; shadow: a bf16 copy of p's shape, or the
     [2, *p.shape] bf16 planes (hi, lo) of a C2_BF16X3P operand."""
+    arr, n = _adam_table(entries)
+    check(lib.c2_adam_step(arr, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                           float(clip_value), int(step_t), stream()))
+
+
+def _adam_table(entries):
     n = len(entries)
     arr = (L.AdamTensor * max(n, 1))()
     for i, (p, g, m, v, sh) in enumerate(entries):
@@ -496,8 +502,38 @@ def adam_step(entries, lr, beta1, beta2, eps, weight_decay, clip_value, step_t):
                 sh, lo = sh[0], sh[1]
             assert sh.numel() == p.numel()
         arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo))
-    check(lib.c2_adam_step(arr, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                           float(clip_value), int(step_t), stream()))
+    return arr, n
+
+
+def adam_state(step, lr, beta1, beta2, eps, weight_decay, clip_value, device):
+    """(state, hyper): the device-resident step state of c2_adam_prepare / c2_adam_step_dev (c2_adam_state: an int64
+    step count followed by six doubles, held as 7 x 8 bytes) and the block its kernel constants are written to."""
+    import numpy as np
+    host = np.zeros(7, dtype=np.float64)
+    host[1:] = (lr, beta1, beta2, eps, weight_decay, clip_value)
+    host[:1].view(np.int64)[0] = int(step)
+    state = torch.from_numpy(host).to(device)
+    hyper = torch.zeros(int(lib.c2_adam_hyper_bytes()), dtype=torch.uint8, device=device)
+    return state, hyper
+
+
+def adam_state_step(state):
+    """Host read (a sync) of the step count held in a device adam state."""
+    return int(state[:1].view(torch.int64).item())
+
+
+def adam_prepare(state, hyper):
+    L.require_gpu(state, hyper)
+    assert state.dtype == torch.float64 and state.numel() == 7 and state.is_contiguous()
+    assert hyper.dtype == torch.uint8 and hyper.numel() >= int(lib.c2_adam_hyper_bytes())
+    check(lib.c2_adam_prepare(ptr(state), ptr(hyper), stream()))
+
+
+def adam_step_dev(entries, hyper):
+    """adam_step with the step's constants in device memory (after adam_prepare)."""
+    arr, n = _adam_table(entries)
+    L.require_gpu(hyper)
+    check(lib.c2_adam_step_dev(arr, n, ptr(hyper), stream()))
 
 
 def cast_bf16(src, dst):
@@ -545,6 +581,27 @@ def scale4(g_dev, weights, out4):
     return out4
 
 
+def combine_losses_dev(losses4, w_dev, out6, accum6=None):
+    """combine_losses with the four weights in device memory; accum6 (float64 [6]) += out6."""
+    L.require_gpu(losses4, w_dev, out6)
+    assert losses4.dtype == torch.float32 and losses4.numel() == 4 and out6.dtype == torch.float32 and out6.numel() == 6
+    assert w_dev.dtype == torch.float32 and w_dev.numel() == 4 and w_dev.is_contiguous()
+    if accum6 is not None:
+        assert accum6.is_cuda and accum6.dtype == torch.float64 and accum6.numel() == 6 and accum6.is_contiguous()
+    check(lib.c2_combine_losses_dev(ptr(losses4), ptr(w_dev), ptr(out6), ptr(accum6), stream()))
+    return out6
+
+
+def scale4_dev(g_dev, w_dev, out4):
+    L.require_gpu(out4, w_dev)
+    assert out4.dtype == torch.float32 and out4.numel() == 4
+    assert w_dev.dtype == torch.float32 and w_dev.numel() == 4 and w_dev.is_contiguous()
+    if g_dev is not None:
+        assert g_dev.dtype == torch.float32 and g_dev.numel() == 1 and g_dev.is_cuda
+    check(lib.c2_scale4_dev(ptr(g_dev), ptr(w_dev), ptr(out4), stream()))
+    return out4
+
+
 def scale(x, a_dev, y):
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib.c2_scale(ptr(x), ptr(a_dev), ptr(y), x.numel(), stream()))
@@ -560,4 +617,15 @@ def dropout_masks(out, p_drop, seed, offset):
     L.require_gpu(out)
     assert out.dtype == torch.uint8 and out.is_contiguous()
     check(lib.c2_dropout_masks(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), int(offset), stream()))
+    return out
+
+
+def dropout_masks_dev(out, p_drop, seed, offset_dev, advance):
+    """dropout_masks with the counter offset in device memory (int64 [1], read as uint64); it is advanced by `advance`
+    after the masks are drawn."""
+    L.require_gpu(out, offset_dev)
+    assert out.dtype == torch.uint8 and out.is_contiguous()
+    assert offset_dev.dtype == torch.int64 and offset_dev.numel() == 1
+    check(lib.c2_dropout_masks_dev(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), ptr(offset_dev),
+                                   int(advance), stream()))
     return out

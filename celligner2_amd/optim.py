@@ -5,6 +5,11 @@ Semantics = torch.optim.Adam as the reference trainer builds it
 bias-corrected moments, `eps` added to sqrt(v_hat).  `param_groups[i]["lr"]` may be changed
 between steps (trainer.py:365-368).  One kernel launch updates every tensor of a group and, in
 bf16 mode, refreshes the bf16 weight shadows the GEMMs read.
+
+`capturable=True` keeps the step count and the hyper-parameters in device memory (c2_adam_prepare /
+c2_adam_step_dev), so that the launches of one step are the same bytes every step and the step can be
+replayed as a HIP graph: `sync_hyper()` carries a changed `lr` over (outside the graph), `replayed()`
+does the host-side bookkeeping of one replay.
 """
 import torch
 
@@ -13,9 +18,14 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0,
-                 shadow_lookup=None, grad_sync=None, on_updated=None):
+                 shadow_lookup=None, grad_sync=None, on_updated=None, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
         super().__init__(params, defaults)
+        if capturable and grad_sync is not None:
+            raise ValueError("a capturable step has no gradient exchange: one process, one GPU")
+        self.capturable = bool(capturable)
+        self._last = None  # (touched, refreshed) parameters of the latest step, for replayed()
+        self._dev = {}     # id(group) -> device-resident step state
         self._shadow_lookup = shadow_lookup  # callable(param) -> bf16 shadow / planes tensor or None
         # The kernel writes the parameters through raw pointers; step() then advances each parameter's autograd version
         # counter (as an in-place torch op would), so that anything caching a function of the weights sees the change.
@@ -27,7 +37,70 @@ class FusedAdam(torch.optim.Optimizer):
         if grad_sync is not None:
             grad_sync.defer_last = True
 
+    @staticmethod
+    def _hyper_of(group):
+        return (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
+                group.get("clip_value", 0.0))
+
+    def _device_state(self, group, step_before, device):
+        """The group's device-resident step state; (re)built from the host's numbers when absent or when the host's
+        step count has moved without it (a loaded state_dict)."""
+        ds = self._dev.get(id(group))
+        if ds is None or ds["step"] != step_before or ds["device"] != device:
+            hyper = self._hyper_of(group)
+            state, block = ops.adam_state(step_before, *hyper, device)
+            ds = self._dev[id(group)] = dict(state=state, block=block, step=step_before, hyper=hyper, device=device)
+        return ds
+
+    def sync_hyper(self):
+        """Write hyper-parameters the host has changed since the last step (the trainer's learning-rate decay,
+        trainer.py:365-368) into the device state.  A few python compares per call when nothing changed."""
+        for group in self.param_groups:
+            ds = self._dev.get(id(group))
+            if ds is not None and ds["hyper"] != self._hyper_of(group):
+                ds["hyper"] = hyper = self._hyper_of(group)
+                ds["state"][1:].copy_(torch.tensor(hyper, dtype=torch.float64), non_blocking=False)
+
+    def replayed(self):
+        """Host-side bookkeeping of ONE replay of a captured step(): step counts, version counters, operand-copy
+        records -- what step() itself does after its launches."""
+        for group in self.param_groups:
+            ds = self._dev.get(id(group))
+            if ds is not None:
+                ds["step"] += 1
+        if self._last is not None:
+            touched, refreshed = self._last
+            for p in touched:
+                self.state[p]["step"] += 1
+            self._publish(touched, refreshed)
+
+    def captured(self):
+        """Call after a step() that ran under stream capture: its launches were recorded, not executed, so the step
+        counts it advanced on the host are taken back (the first replay performs that step)."""
+        for group in self.param_groups:
+            ds = self._dev.get(id(group))
+            if ds is not None:
+                ds["step"] -= 1
+        if self._last is not None:
+            for p in self._last[0]:
+                self.state[p]["step"] -= 1
+
+    def _publish(self, touched, refreshed):
+        if touched:
+            torch._C._autograd._unsafe_set_version_counter(tuple(touched), tuple(p._version + 1 for p in touched))
+            if self._on_updated is not None:
+                for p in refreshed:
+                    self._on_updated(p)
+
     def _launch(self, group, entries, step_t):
+        if self.capturable:
+            ds = self._device_state(group, step_t - 1, entries[0][0].device)
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()
+            ops.adam_prepare(ds["state"], ds["block"])
+            ops.adam_step_dev(entries, ds["block"])
+            ds["step"] = step_t
+            return
         rng = self._grad_sync.deferred_range() if self._grad_sync is not None else None
         hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
                  group.get("clip_value", 0.0), step_t)
@@ -63,6 +136,9 @@ class FusedAdam(torch.optim.Optimizer):
                 if step_t is None:
                     step_t = st["step"]
                 elif step_t != st["step"]:
+                    if self.capturable:
+                        raise RuntimeError("capturable FusedAdam: every tensor of a group must have taken the same "
+                                           "number of steps (one device-resident step count per group)")
                     # tensors that joined later: flush what we have and start a new launch
                     self._launch(group, entries, step_t)
                     entries, step_t = [], st["step"]
@@ -76,9 +152,6 @@ class FusedAdam(torch.optim.Optimizer):
                 self._launch(group, entries, step_t)
         if self._grad_sync is not None:
             self._grad_sync.wait_deferred()  # nothing of the step may outlive it un-synchronised
-        if touched:
-            torch._C._autograd._unsafe_set_version_counter(tuple(touched), tuple(p._version + 1 for p in touched))
-            if self._on_updated is not None:
-                for p in refreshed:
-                    self._on_updated(p)
+        self._last = (touched, refreshed)
+        self._publish(touched, refreshed)
         return loss

@@ -11,6 +11,11 @@ What is different underneath: the dataset is resident in HBM and a batch is gath
 (`_Loader`); loss -> zero_grad -> backward -> clip -> Adam runs in the HIP library (clipping inside the fused Adam
 kernel); per-iteration loss scalars stay on the device and are averaged once per epoch (`log_sync="epoch"`) instead of
 six `.item()` syncs per step (`log_sync="step"` reproduces the reference's per-step floats and error timing).
+
+`graph=True` (one GPU, rng="device"): after two ordinary steps the whole iteration -- gather of the batch's rows,
+forward, backward, Adam -- is captured once as a HIP graph and every further full-size batch is ONE graph launch
+(`_StepGraph`); what changes between steps (row indices, KL weight, learning rate, step count, dropout counter, loss
+sums) lives in device memory.  Short last batches and validation run the ordinary way.
 """
 from __future__ import annotations
 
@@ -93,6 +98,14 @@ def print_progress(epoch, logs, n_epochs=10000, only_val_losses=True):
     sys.stdout.flush()
 
 
+class _StaticBatch:
+    """What a loader in static mode yields for a full-size batch: the rows are already in `loader.static_rows` (a
+    persistent device buffer a captured step reads); `loader.gather_static()` materialises the batch dict."""
+
+    def __init__(self, loader, n):
+        self.loader, self.n = loader, n
+
+
 class _Loader:
     """Index stream of the reference's DataLoader(+WeightedRandomSampler / shuffle) served from a DeviceDataset.
 
@@ -114,6 +127,13 @@ class _Loader:
         self.xin_dtype, self.apply_log = xin_dtype, apply_log
         self.world = world
         self._bufs = {}
+        self.static = False      # full-size batches are handed over as _StaticBatch (Trainer(graph=True))
+        self.static_rows = None  # int64 [batch_size] on the device
+
+    def gather_static(self):
+        n = self.static_rows.numel()
+        return self.ds.gather(self.static_rows, self.xin_dtype, self.apply_log, self._bufs.setdefault(("static", n), {}),
+                              self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(n))
 
     def __len__(self):
         n = self.num_samples if self.weights is not None else len(self.ds)
@@ -145,6 +165,12 @@ class _Loader:
                 if per == 0:
                     continue
                 sub = sub[self.world.rank * per:(self.world.rank + 1) * per]
+            if self.static and sub.numel() == self.bs:
+                if self.static_rows is None:
+                    self.static_rows = torch.empty(self.bs, dtype=torch.int64, device=idx.device)
+                self.static_rows.copy_(sub)
+                yield _StaticBatch(self, self.bs)
+                continue
             yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}),
                                  self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(sub.numel()))
 
@@ -157,6 +183,92 @@ _POPPED = (("alpha_iter_anneal", None), ("n_samples", None), ("train_frac", 0.7)
            ("rng", "reference"),    # index stream / noise on torch's CPU generator, in the reference's order
            ("world", None),         # parallel.DataParallelStep of a one-process-per-GPU run
            ("graph", False))        # replay the step as a captured HIP graph (fixed-shape batches only)
+
+
+class _StepGraph:
+    """One training iteration as a HIP graph.
+
+    The first WARMUP calls run the iteration eagerly (every workspace gets allocated, the optimizer state and the
+    operand copies reach their steady state), the next call captures it, and from then on `step()` is: write what
+    changed on the host into device memory (KL weight, learning rate -- only when they changed), launch the graph,
+    do the optimizer's host-side bookkeeping.  The six loss scalars of every step are summed on the device (float64)
+    and read once per epoch by `drain()`.
+
+    Valid while the model keeps its engine (no parameter replaced, frozen, moved), stays in training mode and the
+    optimizer is the one captured: `alive()` checks that, and the trainer drops the graph otherwise."""
+
+    WARMUP = 2
+
+    def __init__(self, trainer):
+        self.trainer, self.graph, self.calls, self.count = trainer, None, 0, 0
+        dev = trainer.device
+        self.alpha = trainer.calc_alpha_coeff()
+        self.weights = torch.tensor([1.0, self.alpha, 1.0, 1.0], dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(6, dtype=torch.float64, device=dev)
+        self.unit = torch.ones((), device=dev)
+        self.optimizer = trainer.optimizer
+        self.engine = None
+        self.total = None
+        self.scratch = None
+        trainer.model.loss_sums(self.sums)
+        trainer.model.device_noise_counter(True)
+
+    def _iteration(self):
+        t = self.trainer
+        batch = t.dataloader_train.gather_static()
+        total, _ = t.model.forward_total(self.weights, **batch)
+        t.optimizer.zero_grad()
+        total.backward(gradient=self.unit)
+        t.optimizer.step()
+        return total
+
+    def alive(self):
+        t = self.trainer
+        return (t.optimizer is self.optimizer and t.model.training
+                and (self.engine is None or t.model.__dict__.get("_eng") is self.engine))
+
+    def step(self):
+        t = self.trainer
+        alpha = t.calc_alpha_coeff()
+        if alpha != self.alpha:
+            self.alpha = alpha
+            self.weights[1:2].fill_(alpha)
+        if self.graph is None and self.calls >= self.WARMUP:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            engine = t.model._engine()
+            engine.recorded = self.scratch = []  # the graph owns every scratch tensor its kernels address
+            try:
+                with torch.cuda.graph(graph):
+                    self.total = self._iteration()
+            finally:
+                engine.recorded = None
+            t.optimizer.captured()  # recorded, not run: the replay below performs this step
+            self.graph, self.engine = graph, engine
+        if self.graph is not None:
+            t.optimizer.sync_hyper()
+            self.graph.replay()
+            t.optimizer.replayed()
+        else:
+            self.total = self._iteration()
+        self.calls += 1
+        self.count += 1
+        return self.total
+
+    def drain(self):
+        """(sums [6] as python floats, number of steps) since the last call; one host read."""
+        if self.count == 0:
+            return None, 0
+        sums, n = self.sums.tolist(), self.count
+        self.sums.zero_()
+        self.count = 0
+        return sums, n
+
+    def close(self):
+        model = self.trainer.model
+        model.loss_sums(None)
+        model.device_noise_counter(False)
+        self.graph = None
 
 
 class Trainer:
@@ -193,6 +305,11 @@ class Trainer:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.model.to(self.device)
         self.model.rng_mode = self.rng
+        self._graph = None
+        if self.graph:
+            if self.world is not None or self.rng != "device" or self.log_sync != "epoch":
+                raise ValueError("graph=True replays the step on one GPU with device-side noise and per-epoch logs: "
+                                 "it needs world=None, rng='device' and log_sync='epoch'")
         if self.world is not None:
             self.world.attach_model(self.model)
         if staged is not None:  # DeviceDataset objects staged by the caller (adata may be None)
@@ -231,6 +348,7 @@ class Trainer:
                                                  torch.tensor(self.train_data.stratifier_weights), self.n_samples)
         else:                             # shuffle=True
             self.dataloader_train = self._loader(self.train_data, self.batch_size, None, None)
+        self.dataloader_train.static = bool(self.graph)
         if self.valid_data is not None:
             self.val_iters_per_epoch = int(np.ceil(len(self.valid_data) / self.batch_size))
             self.dataloader_valid = self._loader(self.valid_data, min(self.batch_size, len(self.valid_data)), None, None)
@@ -241,7 +359,15 @@ class Trainer:
         lookup, updated = self.model._adam_hooks()
         return FusedAdam([p for p in self.model.parameters() if p.requires_grad], lr=lr, eps=eps,
                          weight_decay=self.weight_decay, clip_value=self.clip_value, shadow_lookup=lookup,
-                         on_updated=updated, grad_sync=self.world)
+                         on_updated=updated, grad_sync=self.world, capturable=bool(self.graph))
+
+    def drop_graph(self):
+        """Forget the captured step (the next full-size batch starts a new warm-up and capture); the loss sums it
+        holds are folded into the current epoch's logs first."""
+        if self._graph is not None:
+            self._bank_graph_sums()
+            self._graph.close()
+            self._graph = None
 
     def calc_alpha_coeff(self):
         """KL weight in force (trainer.py:231-253): linear ramp over epochs or over iterations up to alpha_kl."""
@@ -259,6 +385,7 @@ class Trainer:
         started = time.time()
         self.model.train()
         self.n_epochs = n_epochs
+        self.drop_graph()
         self.optimizer = self.make_optimizer(lr, eps)
         self.before_loop()
         for self.epoch in range(n_epochs):
@@ -273,6 +400,7 @@ class Trainer:
             # (the snapshot is the live state_dict, as in the reference: trainer.py:359 keeps no copy)
             print(f"Reloading the best state (epoch {self.best_epoch}) into the network")
             self.model.load_state_dict(self.best_state_dict)
+        self.drop_graph()
         self.model.eval()
         self.after_loop()
         self.model._engine().check_status()
@@ -297,6 +425,13 @@ class Trainer:
         """One optimisation step (trainer.py:305-323)."""
         if getattr(self.model, "freeze", False):
             self._unhook_frozen_batchnorm()
+        if isinstance(batch_data, _StaticBatch):
+            if self._graph is not None and not self._graph.alive():
+                self.drop_graph()
+            if self._graph is None:
+                self._graph = _StepGraph(self)
+            self.current_loss = self._graph.step()
+            return
         self.current_loss = loss = self.loss(batch_data)
         self.optimizer.zero_grad()
         seed = self.__dict__.get("_unit")
@@ -311,9 +446,35 @@ class Trainer:
             return float(torch.stack(values).double().mean().item())
         return float(np.array(values).mean())
 
+    # (log key, position in the model's loss vector) of what a captured step sums on the device; the subclass that
+    # defines `loss` says which entries it logs
+    _LOGGED = ()
+
+    def _bank_graph_sums(self):
+        """Move the captured steps' device-side loss sums into `_banked` (key -> [sum, steps])."""
+        sums, n = self._graph.drain() if self._graph is not None else (None, 0)
+        if n:
+            bank = self.__dict__.setdefault("_banked", {})
+            for key, pos in self._LOGGED:
+                if key != "mmd_loss" or self.model.use_mmd:
+                    entry = bank.setdefault(key, [0.0, 0])
+                    entry[0] += sums[pos]
+                    entry[1] += n
+
     def _fold_iter_logs(self, prefix):
-        for key, values in self.iter_logs.items():
-            self.logs[prefix + key].append(self._epoch_mean(values))
+        bank = {}
+        if prefix == "epoch_":
+            self._bank_graph_sums()
+            bank = self.__dict__.pop("_banked", {})
+        for key in list(bank) + [k for k in self.iter_logs if k not in bank]:
+            values = self.iter_logs.get(key, [])
+            if key in bank:  # steps replayed from the graph, plus whatever ran the ordinary way (a short last batch)
+                total, n = bank[key]
+                if len(values):
+                    total += self._epoch_mean(values) * len(values)
+                self.logs[prefix + key].append(total / (n + len(values)))
+            else:
+                self.logs[prefix + key].append(self._epoch_mean(values))
 
     def on_epoch_end(self):
         self._fold_iter_logs("epoch_")
@@ -355,6 +516,9 @@ class Celligner2Trainer(Trainer):
 
     def __init__(self, model, adata, **kwargs):
         super().__init__(model, adata, **kwargs)
+        if self.graph and type(self).loss is not Celligner2Trainer.loss:
+            raise ValueError("graph=True captures Celligner2Trainer's own loss; a subclass that overrides `loss` "
+                             "must run with graph=False")
 
     def loss(self, total_batch=None):
         """semisupervised.py:63-74: `loss = recon + alpha*kl + mmd + ce` (:66) and `unweighted_loss = recon + kl + mmd`

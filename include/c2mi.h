@@ -240,6 +240,20 @@ typedef struct {
 int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
                  double weight_decay, double clip_value, int64_t step_t, void* stream);
 
+/* The same step with its state ON THE DEVICE, for a training step replayed as a HIP graph (a graph bakes every by-value
+ * argument in; torch's capturable optimizers keep `step` on the device for the same reason).  No counterpart in the
+ * reference.  c2_adam_prepare: *state_dev.step += 1, then the kernel constants (bias corrections formed in double, as
+ * c2_adam_step forms them on the host) into hyper_dev (c2_adam_hyper_bytes() bytes of device memory);
+ * c2_adam_step_dev: the update of c2_adam_step with the constants read from hyper_dev.  lr may be rewritten between
+ * steps by the host (learning-rate decay): a plain device write to state_dev->lr. */
+typedef struct {
+    int64_t step; /* steps taken so far (0 before the first) */
+    double lr, beta1, beta2, eps, weight_decay, clip_value;
+} c2_adam_state;
+size_t c2_adam_hyper_bytes(void);
+int c2_adam_prepare(c2_adam_state* state_dev, void* hyper_dev, void* stream);
+int c2_adam_step_dev(const c2_adam_tensor* desc_host, int n_tensors, const void* hyper_dev, void* stream);
+
 /* fp32 -> bf16 copy (initial weight shadows), n elements. */
 int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 
@@ -307,6 +321,17 @@ int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float 
 /* Its backward seed: out4[i] = w_i * g (g = *g_dev, or 1 when g_dev is NULL) -- the upstream gradients of the four
  * losses when the weighted total receives gradient g. */
 int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float* out4, void* stream);
+
+/* c2_combine_losses / c2_scale4 with the four weights in device memory (w_dev[4]): the KL weight changes per epoch
+ * (trainer.py:231-253) and a replayed HIP graph cannot take it by value.  accum6 (may be NULL): += out6 in double, the
+ * running sums of an epoch's loss logs (trainer.py:326-328 takes their float64 means) without a host read per step. */
+int c2_combine_losses_dev(const float* losses4, const float* w_dev, float* out6, double* accum6, void* stream);
+int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* stream);
+
+/* c2_dropout_masks with the Philox counter offset in device memory: masks from *offset_dev, then *offset_dev += advance
+ * (a second, one-thread launch), so that every replay of a captured step draws fresh masks. */
+int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev, uint64_t advance,
+                         void* stream);
 
 /* y[i] = a*x[i] (a = *a_dev), fp32. */
 int c2_scale(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
