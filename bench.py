@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="cells per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-pass", action="store_true",
+                    help="warm-up and the K timed steps only (no steady-state loop, no all-terms leg, no CPU baseline): "
+                         "what the rocprofv3 passes run, so that dispatch counts divide by W+K")
     ap.add_argument("--graph", type=int, default=-1, help="1/0: replay the step as a HIP graph (default: the config's)")
     ap.add_argument("--steady-seconds", type=float, default=1.2, help="length of the second, longer timing loop")
     args = ap.parse_args()
@@ -197,7 +200,9 @@ def main():
                        use_mmd=True, mmd_on="z", beta=cfg["beta"], predictors=[f"p{i}" for i in range(cfg["P"])],
                        classifier_hidden_layer_sizes=cfg["cls_hidden"], precision=args.precision)
     data = synth_dataset(cfg, device)
-    use_graph = bool(cfg.get("graph", False)) if args.graph < 0 else bool(args.graph)
+    # one GPU: the step is replayed as a HIP graph unless --graph 0; ranks of a data-parallel run launch it kernel by kernel
+    # (the gradient exchange is not capturable)
+    use_graph = (bool(cfg.get("graph", True)) if args.graph < 0 else bool(args.graph)) and world == 1
     trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=Bglob, use_leiden=False,
                                 alpha_kl=1e-3, monitor=False, use_early_stopping=False, rng="device", world=comm,
                                 seed=2020, n_samples=n_samples, **({"graph": True} if use_graph else {}))
@@ -256,6 +261,9 @@ def main():
         return float(t.item()), int(r.item())
 
     trace("model, dataset and trainer built")
+    if use_graph:  # set-up, like building the model: two ordinary steps, then the step that captures the graph
+        for _ in range(3):
+            step(stream)
     for i in range(args.warmup):
         step(stream)
         trace(f"warmup step {i} launched")
@@ -281,6 +289,13 @@ def main():
     dt, cells = over_ranks(dt, rows)
     # The same pipeline over a longer loop (>= --steady-seconds): the K-step region above lasts tens of milliseconds,
     # too short for a power-managed chip to settle; `value` stays the K-step figure the contract asks for.
+    if args.profile_pass:
+        if rank == 0:
+            print(json.dumps({"profile_pass": True, "steps": args.steps, "warmup": args.warmup, "hip_graph": use_graph,
+                              "ms_per_step": 1e3 * dt / args.steps, "value": cells / dt}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     n_steady = max(args.steps, int(np.ceil(args.steady_seconds / max(dt / args.steps, 1e-6))))
     if world > 1:  # every rank must run the same number of steps
         ns = torch.tensor([n_steady], device=device, dtype=torch.int64)

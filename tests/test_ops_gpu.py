@@ -653,7 +653,7 @@ def test_wgrad_two_part_schedule(by_rows):
     from celligner2_amd.engine import StepEngine
     ops = _ops()
     eng = StepEngine.__new__(StepEngine)
-    eng.x3, eng._ws, eng.dev = False, {}, torch.device(DEV)
+    eng.x3, eng._ws, eng._pool, eng.recorded, eng.dev = False, {}, {}, None, torch.device(DEV)
     M, big, small = 1024, 66 * 256 + 40, 1024
     N, K = (big, small) if by_rows else (small, big)
     g = torch.Generator(device="cpu").manual_seed(7 + by_rows)

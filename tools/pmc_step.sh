@@ -6,8 +6,9 @@ tag=$1
 cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/pmc_step_$tag
 mkdir -p $out
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $out/fetch -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/fetch.log 2>&1 || exit 4
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $out/write -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/write.log 2>&1 || exit 5
-python3 tools/pmc_step_json.py $out > $out/r01_gemm_pmc.json || exit 6
+W=2; K=3
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $out/fetch -- python3 bench.py --profile-pass --graph 0 --steps $K --warmup $W > $out/fetch.log 2>&1 || exit 4
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $out/write -- python3 bench.py --profile-pass --graph 0 --steps $K --warmup $W > $out/write.log 2>&1 || exit 5
+python3 tools/pmc_step_json.py $out $((W + K)) > $out/r02_gemm_pmc.json || exit 6
 rm -rf $out/fetch $out/write
-cat $out/r01_gemm_pmc.json
+cat $out/r02_gemm_pmc.json

@@ -1,6 +1,7 @@
-"""profiles/r01_gemm_pmc.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.sh: HBM bytes per launch of
+"""profiles/r02_gemm_pmc.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.sh: HBM bytes per launch of
 the gene-width GEMM kernel (wide::gemm_wide_kernel<*,*,8,*>) in the real training step.
-HBM bytes = FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE [KB] x 1024."""
+HBM bytes = FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE [KB] x 1024.
+usage: pmc_step_json.py <dir with fetch/ and write/> <steps the profiled command ran (warm-up + timed)>"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -17,24 +18,28 @@ def read(d, counter):
 
 
 def main():
-    out = sys.argv[1]
+    out, steps = sys.argv[1], int(sys.argv[2])
     fe, wr = read(os.path.join(out, "fetch"), "FETCH_SIZE"), read(os.path.join(out, "write"), "WRITE_SIZE")
-    shapes, total, launches = {}, 0.0, 0
+    shapes, total, launches = {}, 0.0, 0.0
     for k in sorted(fe):
         f_kb = sum(fe[k]) / len(fe[k])
         w_kb = sum(wr[k]) / len(wr[k])
+        per_step = len(fe[k]) / steps  # two launches of one step can share kernel instance and grid
         hbm = f_kb * 1024 * 2 + w_kb * 1024
-        shapes[f"{k[0]} grid={k[1]}"] = dict(dispatches_seen=len(fe[k]), fetch_kb=f_kb, write_kb=w_kb, hbm_bytes=hbm)
-        total += hbm
-        launches += 1
+        shapes[f"{k[0]} grid={k[1]}"] = dict(dispatches_seen=len(fe[k]), launches_per_step=per_step, fetch_kb=f_kb,
+                                             write_kb=w_kb, hbm_bytes_per_launch=hbm)
+        total += hbm * per_step
+        launches += per_step
     algorithmic = 1365655552  # operands read once + outputs written once, 5 GEMMs of the C4 step
     print(json.dumps({
-        "source": "tools/pmc_step.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)",
+        "source": "tools/pmc_step.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --profile-pass --graph 0`, "
+                  "separate passes)",
         "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, mean per launch over the step's gene-width GEMM launches "
                 "(5 GEMMs as 7 launches: each wgrad = full rounds + split strip; the encoder's forward and weight gradient "
                 "read the batch in place from the resident matrix)",
-        "shapes": shapes, "hbm_bytes_per_step": total, "algorithmic_bytes_per_step": algorithmic,
-        "launches_per_step": launches, "traffic_bytes_per_launch": total / max(launches, 1)}, indent=1))
+        "steps_profiled": steps, "shapes": shapes, "hbm_bytes_per_step": total,
+        "algorithmic_bytes_per_step": algorithmic, "launches_per_step": launches,
+        "traffic_bytes_per_launch": total / max(launches, 1e-9)}, indent=1))
 
 
 if __name__ == "__main__":

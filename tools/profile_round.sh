@@ -1,0 +1,26 @@
+#!/bin/bash
+# The round's profiles in one GPU call: kernel trace + stats of the bench command (C4 and C2, step replayed as a HIP
+# graph), the HBM-traffic passes of the gene-width GEMMs, and the bench lines themselves.  Every GPU step has its own
+# time limit and the script stops at the first failure.  usage: tools/profile_round.sh <tag>   (GPU box only)
+set -o pipefail
+tag=$1
+cd "$(dirname "$0")/.." || exit 1
+root=$PWD
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for cfg in c4 c2; do
+  steps=20; warm=5
+  [ $cfg = c2 ] && { steps=200; warm=20; }
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/trace_$cfg -- python3 $root/bench.py --profile-pass --config $cfg --steps $steps --warmup $warm > $out/trace_$cfg.log 2>&1 || exit 3
+  db=$(find $out/trace_$cfg -name "*.db" | head -1)
+  python3 $root/tools/rocpd_stats.py $db > $out/${cfg}_kernel_stats.txt || exit 4
+  echo "# python3 bench.py --profile-pass --config $cfg --steps $steps --warmup $warm  (rocprofv3 --kernel-trace --stats; $((steps + warm)) steps + capture)" >> $out/${cfg}_kernel_stats.txt
+  rm -rf $out/trace_$cfg
+done
+cd $root
+bash tools/pmc_step.sh $tag || exit 5
+cp gpurun_out/pmc_step_$tag/r02_gemm_pmc.json $out/ || exit 6
+timeout -k 10 300 python3 bench.py > $out/bench_c4.json 2> $out/bench_c4.err || exit 7
+timeout -k 10 300 python3 bench.py --config c2 --steps 200 --warmup 20 > $out/bench_c2.json 2> $out/bench_c2.err || exit 8
+echo done
