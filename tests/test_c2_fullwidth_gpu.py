@@ -1,0 +1,100 @@
+"""Config C2 at full width (the reference's default regime, trainer.py:73: batches of 128 cells; 19 000 genes, hidden
+[256, 128], latent 16, two conditions, a 30-way classifier [32, 64], MMD with beta 500).  The numpy oracle needs minutes
+per step at this width, so the step is checked through size-independent properties: determinism, invariance under a
+permutation of the batch rows, bf16-operand mode against fp32 mode (which the small fixtures pin to the reference at
+1e-4), and -- the point of this regime -- the step replayed as a HIP graph against the step launched kernel by kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G, HIDDEN, L, C, P, CLS, B, N, BETA = 19000, [256, 128], 16, 2, 30, [32, 64], 128, 1024, 500.0
+
+
+def _data(seed=7):
+    from celligner2_amd.dataset import DeviceDataset
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    gene = torch.exp(torch.randn(1, G, device=DEV, generator=g) * 1.5 + 1.0)
+    depth = torch.empty(N, 1, device=DEV).uniform_(0.5, 2.0, generator=g)
+    X = torch.poisson(depth * gene, generator=g)
+    good = torch.rand(N, G, device=DEV, generator=g) > 0.005
+    cond = torch.zeros(N, C, dtype=torch.int64, device=DEV)
+    cond[torch.arange(N, device=DEV), torch.randint(0, C, (N,), device=DEV, generator=g)] = 1
+    cls = torch.zeros(N, P, dtype=torch.int64, device=DEV)
+    lab = torch.randint(0, P + 3, (N,), device=DEV, generator=g)  # labels >= P: rows without a known class (-1 row)
+    known = lab < P
+    cls[torch.arange(N, device=DEV)[known], lab[known]] = 1
+    cls[~known] = -1
+    return DeviceDataset.from_tensors(X, X.sum(1), good, cond, cls)
+
+
+def _model(precision, dr=0.0):
+    from celligner2_amd.model import Celligner2
+    torch.manual_seed(11)
+    return Celligner2(G, HIDDEN, L, dr, False, "nb", conditions=["a", "b"], use_mmd=True, mmd_on="z", beta=BETA,
+                      predictors=[f"p{i}" for i in range(P)], classifier_hidden_layer_sizes=CLS,
+                      precision=precision).to(DEV).train()
+
+
+def _step(model, batch, eps):
+    model._forced_noise = dict(eps=eps, masks={})
+    for p in model.parameters():
+        p.grad = None
+    total, v = model.forward_total((1.0, 1e-3, 1.0, 1.0), **batch)
+    total.backward(gradient=torch.ones((), device=DEV))
+    model._engine().check_status()
+    return v.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_small_batch_step_properties_at_19k_genes():
+    data = _data()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    idx = torch.randperm(N, device=DEV, generator=g)[:B]
+    eps = torch.randn(B, L, device=DEV, generator=g)
+    m16, m32 = _model("bf16"), _model("fp32")
+    m32.load_state_dict(m16.state_dict())
+    batch = lambda m, rows: data.gather(rows, xin_dtype=m._engine().enc[0].gt, apply_log=True, nb_const=True,  # noqa: E731
+                                        resident_rows=True)
+    v1, g1 = _step(m16, batch(m16, idx), eps)
+    v2, g2 = _step(m16, batch(m16, idx), eps)
+    assert torch.equal(v1, v2) and all(torch.equal(g1[k], g2[k]) for k in g1), "the step is not deterministic"
+    assert torch.isfinite(v1).all() and float(v1[3]) > 0 and float(v1[2]) > 0  # classifier and MMD terms are live
+    # permuting the batch rows (with their noise) permutes nothing the losses or the weight gradients can see
+    perm = torch.randperm(B, device=DEV, generator=g)
+    vp, gp = _step(m16, batch(m16, idx[perm]), eps[perm])
+    assert np.allclose(vp.cpu(), v1.cpu(), rtol=2e-4)
+    for k in g1:
+        assert _l2(gp[k], g1[k]) < 2e-3, (k, _l2(gp[k], g1[k]))
+    # bf16 operands against fp32 operands: losses 1e-2 (north_star), gradients 3e-2 in the L2 norm at this batch size
+    # (128 rows average less rounding noise than the 4096 of C4, where the same check holds 1e-2)
+    v32, g32 = _step(m32, batch(m32, idx), eps)
+    assert np.allclose(v1.cpu(), v32.cpu(), rtol=1e-2), (v1, v32)
+    for k in g32:
+        assert _l2(g1[k], g32[k]) < 3e-2, (k, _l2(g1[k], g32[k]))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_replayed_step_equals_the_launched_step_at_c2(precision):
+    from celligner2_amd.trainer import Celligner2Trainer
+    out = []
+    for graph in (False, True):
+        data = _data()
+        model = _model(precision, dr=0.05)
+        tr = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=B, use_leiden=False,
+                               alpha_kl=1e-3, alpha_iter_anneal=10, monitor=False, use_early_stopping=False, rng="device",
+                               seed=5, graph=graph)
+        tr.train(n_epochs=2, lr=1e-3)  # 8 full batches per epoch: 13 of the 16 steps are replays
+        out.append((model.state_dict(), dict(tr.logs)))
+    (s0, l0), (s1, l1) = out
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), f"{k}: {(s0[k].float() - s1[k].float()).abs().max().item():.3e}"
+    for k in l0:
+        assert np.allclose(l0[k], l1[k], rtol=1e-6), (k, l0[k], l1[k])
+    assert np.isfinite(l1["epoch_loss"]).all() and len(l1["epoch_loss"]) == 2
