@@ -147,7 +147,8 @@ def test_bf16_step_midsize_vs_oracle(use_bn):
     """bf16-MFMA mode at a realistic width (G=4096, hidden [512,256], B=512): losses and every gradient tensor
     within 1e-2 (relative L2) of the fp64 oracle -- the north_star tolerance for bf16 mode.  use_bn: the
     BatchNorm1d variant: losses, activations and running statistics hold 1e-2 as well, its GRADIENTS are bounded at
-    8e-2 (measured 2-5 %).  Reason: BatchNorm's backward removes the batch-mean component of the incoming gradient,
+    model.BF16_BATCHNORM_GRADIENT_BOUND = 8e-2 (measured 2-5 %) -- a documented exception of the API, announced by a
+    warning at construction (checked here) and in INTEGRATION.md, not a parity claim.  Reason: BatchNorm's backward removes the batch-mean component of the incoming gradient,
     and at initialisation that component dominates (every cell pulls the decoder the same way), so the 2^-9
     rounding of the bf16 operands (dlogits, the encoder input) is a ~10x larger fraction of what is left.  This is
     a property of bf16 operands under BatchNorm, not of the kernels: the same model in fp32 mode matches the
@@ -183,8 +184,13 @@ def test_bf16_step_midsize_vs_oracle(use_bn):
     eps = rng.standard_normal((B, L)).astype(np.float32)
     ref = orc.forward_backward({k: v.astype(np.float64) for k, v in params.items()}, cfg, batch, eps.astype(np.float64),
                                gscale=(1, 1e-3, 1, 1), buffers=buffers)
-    m = Celligner2(G, hidden, L, 0.0, False, "nb", use_bn, conditions=[f"c{i}" for i in range(C)], use_mmd=True,
-                   beta=100.0, predictors=[f"p{i}" for i in range(P)], precision="bf16")
+    import warnings
+    from celligner2_amd.model import BF16_BATCHNORM_GRADIENT_BOUND
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        m = Celligner2(G, hidden, L, 0.0, False, "nb", use_bn, conditions=[f"c{i}" for i in range(C)], use_mmd=True,
+                       beta=100.0, predictors=[f"p{i}" for i in range(P)], precision="bf16")
+    assert any("use_bn=True" in str(w.message) for w in caught) == use_bn
     m.load_state_dict({k: torch.tensor(v) for k, v in {**params, **buffers}.items()})
     m.to(DEV).train()
     m._forced_noise = dict(eps=torch.tensor(eps).to(DEV), masks={})
@@ -200,7 +206,7 @@ def test_bf16_step_midsize_vs_oracle(use_bn):
         if use_bn and n.endswith(".bias") and n[:-4] + "weight" in ref["grads"]:  # cancelling batch sums: gu.grad_err
             den = max(den, np.linalg.norm(ref["grads"][n[:-4] + "weight"]))
         err = np.linalg.norm(g - gr) / max(den, 1e-30)
-        assert err < (8e-2 if use_bn else 1e-2), (n, err)
+        assert err < (BF16_BATCHNORM_GRADIENT_BOUND if use_bn else 1e-2), (n, err)
     for blk in ("enc0", "enc1", "dec0", "dec1"):  # normalised activations of every block
         yh = m._engine()._ws[blk + ".yhat"].double().cpu().numpy()
         assert np.linalg.norm(yh - ref["caches"][blk]["yhat"]) / np.linalg.norm(yh) < 1e-2, blk
