@@ -178,7 +178,8 @@ def main():
             print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
         from celligner2_amd.parallel import DataParallelStep
-        comm = DataParallelStep()
+        # reduce-scatter -> Adam on the rank's own chunks -> all-gather (C2_BENCH_SHARD=0: all-reduce, Adam everywhere)
+        comm = DataParallelStep(shard_optimizer=os.environ.get("C2_BENCH_SHARD", "1") != "0")
 
     from celligner2_amd import ops
     from celligner2_amd.model import Celligner2
@@ -357,6 +358,8 @@ def main():
                                    f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
                        "global_batch": Bglob, "parallelism": f"dp{n_gpus}", "backend": backend if world > 1 else None,
                        "epoch_rows": n_samples, "hip_graph": use_graph,
+                       "optimizer": ("sharded over ranks (reduce-scatter, Adam on own chunks, all-gather)"
+                                     if (comm is not None and comm.sharded) else "every rank updates every parameter"),
                        "dataset_resident_terms": "log(1+x) as bf16 and the per-row sum of lgamma(x+1) are evaluated once "
                                                  "per dataset (identical values); see all_terms_in_step for the step "
                                                  "that evaluates them per batch like the reference's forward"},

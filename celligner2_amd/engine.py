@@ -158,34 +158,59 @@ class StepEngine:
         return out
 
     def _build_arena(self):
-        """One flat fp32 gradient arena (views per parameter) cut into three all-reduce buckets:
-        [decoder output layer + theta] [everything between] [encoder L0]."""
-        key = tuple((n, tuple(p.shape), p.requires_grad) for n, p in self.p.items())
+        """One flat fp32 gradient arena (views per parameter) cut into three exchange buckets:
+        [decoder output layer + theta] [everything between] [encoder L0].
+
+        With a sharding communicator (parallel.DataParallelStep(shard_optimizer=True)) every bucket's length is a
+        multiple of 64 x world_size, so that it cuts into equal 256-byte-aligned chunks, one per rank, and the trainable
+        parameters themselves become views of a second flat buffer with the SAME offsets (`param_flat`): the bucket is
+        reduce-scattered, each rank runs Adam on its chunk, and the chunk is all-gathered in place."""
+        sharded = self.comm is not None and getattr(self.comm, "sharded", False) and self.world_size > 1
+        key = (tuple((n, tuple(p.shape), p.requires_grad) for n, p in self.p.items()), sharded, self.world_size)
         if getattr(self, "_arena_key", None) == key:
             return
         self._arena_key = key
         names = [n for n in self._readiness_order() if self.p[n].requires_grad]
-        # the two latent heads' weights (and biases) lie back to back, so that one [2L, H] ([2L]) view spans both
-        glued = {self.HEADS[1] + ".weight": self.HEADS[0] + ".weight", self.HEADS[1] + ".bias": self.HEADS[0] + ".bias"}
-        offs, total, prev = {}, 0, None
-        for n in names:
-            if prev is not None and glued.get(n) == prev and self.p[prev].numel() % 4 == 0:  # (16-byte alignment)
-                total = offs[prev] + self.p[prev].numel()
-            offs[n] = total
-            total += (self.p[n].numel() + 63) // 64 * 64
-            prev = n
-        self.grad_flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
-        self.grad = {n: self.grad_flat[offs[n]:offs[n] + self.p[n].numel()].view(self.p[n].shape) for n in names}
         first = {self.head + ".weight", self.head + ".bias", "theta"}
         if self.head2:
             first |= {self.head2 + ".weight", self.head2 + ".bias"}
         last = {self.enc[0].w, self.enc[0].b, self.enc[0].wc}
         if self.enc[0].norm:
             last |= {self.enc[0].norm + ".weight", self.enc[0].norm + ".bias"}
+        quantum = 64 * (self.world_size if sharded else 1)
+        up = lambda v: (v + quantum - 1) // quantum * quantum  # noqa: E731
+        part = lambda n: 0 if n in first else (2 if n in last else 1)  # noqa: E731
+        # the two latent heads' weights (and biases) lie back to back, so that one [2L, H] ([2L]) view spans both
+        glued = {self.HEADS[1] + ".weight": self.HEADS[0] + ".weight", self.HEADS[1] + ".bias": self.HEADS[0] + ".bias"}
+        offs, total, prev = {}, 0, None
+        for n in names:
+            if prev is not None and part(n) != part(prev):
+                total = up(total)  # a bucket starts on a chunk boundary
+            if prev is not None and glued.get(n) == prev and self.p[prev].numel() % 4 == 0:  # (16-byte alignment)
+                total = offs[prev] + self.p[prev].numel()
+            offs[n] = total
+            total += (self.p[n].numel() + 63) // 64 * 64
+            prev = n
+        total = up(total)
+        self.grad_flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
+        self.grad = {n: self.grad_flat[offs[n]:offs[n] + self.p[n].numel()].view(self.p[n].shape) for n in names}
         ends = {n: offs[n] + (self.p[n].numel() + 63) // 64 * 64 for n in names}
-        b0 = max([ends[n] for n in names if n in first], default=0)            # readiness order: `first` leads,
+        b0 = up(max([ends[n] for n in names if n in first], default=0))        # readiness order: `first` leads,
         lo2 = min([offs[n] for n in names if n in last], default=total)        # `last` closes the arena
         self.buckets = [(0, b0), (b0, lo2), (lo2, total)]
+        self.param_flat = None
+        if sharded:
+            flat = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
+            for n in names:
+                prm = self.p[n]
+                view = flat[offs[n]:offs[n] + prm.numel()].view(prm.shape)
+                view.copy_(prm.detach())
+                prm.data = view
+            self.param_flat = flat
+            self._ws.pop("heads.W", None)  # the stacked view of the heads is rebuilt over the new storage
+            self._ws.pop("heads.b", None)
+            self._wplanes.pop(self.HEADW, None)
+            self.comm.set_arena(self.grad_flat, flat, self.buckets)
 
     def gbuf(self, name):
         self._build_arena()
@@ -196,7 +221,7 @@ class StepEngine:
         if self.comm is not None and self.world_size > 1:
             lo, hi = self.buckets[i]
             if hi > lo:
-                self.comm.allreduce_bucket_async(self.grad_flat[lo:hi])
+                self.comm.reduce_bucket_async(self.grad_flat[lo:hi])
 
     def weight(self, name):
         """GEMM operand view of a weight: the fp32 parameter itself, or its bf16 shadow."""
@@ -263,12 +288,22 @@ class StepEngine:
     HEADS = ("encoder.mean_encoder", "encoder.log_var_encoder")
     HEADW = "@heads"  # virtual weight name of the stacked matrix
 
+    @staticmethod
+    def _back_to_back(a, b):
+        return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.is_contiguous()
+                and b.is_contiguous() and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size())
+
     def _heads_fusable(self):
         wm, wl = (self.p[h + ".weight"] for h in self.HEADS)
         bm, bl = (self.p[h + ".bias"] for h in self.HEADS)
-        return (wm.shape == wl.shape and self.gemm_dtype(self.HEADS[0] + ".weight") == F32
-                and wm.requires_grad == wl.requires_grad and bm.requires_grad == bl.requires_grad
-                and wm.dtype == F32 and wl.dtype == F32 and wm.numel() % 4 == 0 and bm.numel() % 4 == 0)
+        ok = (wm.shape == wl.shape and self.gemm_dtype(self.HEADS[0] + ".weight") == F32
+              and wm.requires_grad == wl.requires_grad and bm.requires_grad == bl.requires_grad
+              and wm.dtype == F32 and wl.dtype == F32 and wm.numel() % 4 == 0 and bm.numel() % 4 == 0)
+        if ok and getattr(self, "param_flat", None) is not None and wm.requires_grad:
+            # the parameters are views of the sharded flat buffer and must stay there: fuse only where they lie
+            # back to back in it (they do whenever the arena could glue them)
+            ok = self._back_to_back(wm.data, wl.data) and self._back_to_back(bm.data, bl.data)
+        return ok
 
     def _fuse_heads(self):
         """Make (or keep) the two heads' parameters views of the stacked buffers; returns (W [2L,H], b [2L])."""
@@ -281,10 +316,15 @@ class StepEngine:
               and wl.data_ptr() == W[L:].data_ptr() and bm.data_ptr() == b.data_ptr()
               and bl.data_ptr() == b[L:].data_ptr())
         if not ok:
-            W = torch.cat([wm.detach(), wl.detach()], 0).contiguous()
-            b = torch.cat([bm.detach(), bl.detach()], 0).contiguous()
-            wm.data, wl.data = W[:L], W[L:]
-            bm.data, bl.data = b[:L], b[L:]
+            if self._back_to_back(wm.data, wl.data) and self._back_to_back(bm.data, bl.data):
+                # already adjacent in one storage (the sharded flat parameter buffer): views, nothing moves
+                W = wm.detach().as_strided((2 * L, H), (H, 1), wm.storage_offset())
+                b = bm.detach().as_strided((2 * L,), (1,), bm.storage_offset())
+            else:
+                W = torch.cat([wm.detach(), wl.detach()], 0).contiguous()
+                b = torch.cat([bm.detach(), bl.detach()], 0).contiguous()
+                wm.data, wl.data = W[:L], W[L:]
+                bm.data, bl.data = b[:L], b[L:]
             self._ws["heads.W"], self._ws["heads.b"] = W, b
             self._wplanes.pop(self.HEADW, None)
         return W, b
@@ -586,6 +626,7 @@ class StepEngine:
         # stale one (two forwards before one backward would silently differentiate the second)
         if save:
             self.generation = getattr(self, "generation", 0) + 1
+            self._build_arena()  # (sharded form: the parameters move into the flat buffer BEFORE anything reads them)
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
         pre = batch.get("xin")  # already produced by the device-resident gather

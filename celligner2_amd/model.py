@@ -141,6 +141,9 @@ def _keep_accumulated(model, eng):
     lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
     for p in model._param_list:
         if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+            if eng.comm is not None and getattr(eng.comm, "sharded", False):
+                raise NotImplementedError("gradient accumulation is not available with shard_optimizer=True (a rank "
+                                          "holds only its own chunk of the reduced gradient); call zero_grad() first")
             if eng.comm is not None:
                 eng.comm.wait_deferred()  # the bucket an earlier backward left in flight must have landed first
             p.grad = p.grad.clone()
@@ -159,6 +162,9 @@ def _hand_over(model, eng, grads):
                 p.grad = grads[n]
         return tuple(None for _ in params)
     if eng.comm is not None:
+        if getattr(eng.comm, "sharded", False):
+            raise NotImplementedError("gradient accumulation is not available with shard_optimizer=True (a rank holds "
+                                      "only its own chunk of the reduced gradient); call zero_grad() first")
         eng.comm.wait_deferred()
     return tuple((grads[n].clone() if (p.requires_grad and n in grads) else None) for n, p in zip(names, params))
 

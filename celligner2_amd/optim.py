@@ -37,6 +37,9 @@ class FusedAdam(torch.optim.Optimizer):
         if grad_sync is not None:
             grad_sync.defer_last = True
 
+    def _sharded(self):
+        return self._grad_sync is not None and getattr(self._grad_sync, "sharded", False)
+
     @staticmethod
     def _hyper_of(group):
         return (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
@@ -101,6 +104,8 @@ class FusedAdam(torch.optim.Optimizer):
             ops.adam_step_dev(entries, ds["block"])
             ds["step"] = step_t
             return
+        if self._sharded():  # this rank updates only the elements whose reduced gradient it received
+            entries = self._grad_sync.owned_parts(entries)
         rng = self._grad_sync.deferred_range() if self._grad_sync is not None else None
         hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
                  group.get("clip_value", 0.0), step_t)
@@ -143,7 +148,9 @@ class FusedAdam(torch.optim.Optimizer):
                     self._launch(group, entries, step_t)
                     entries, step_t = [], st["step"]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                sh = self._shadow_lookup(p) if self._shadow_lookup is not None else None
+                # (sharded form: the kernel sees a chunk of the tensor only, so the operand copies are converted by the
+                # engine after the all-gather -- the version counters advanced below tell it to)
+                sh = self._shadow_lookup(p) if (self._shadow_lookup is not None and not self._sharded()) else None
                 entries.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], sh))
                 touched.append(p)
                 if sh is not None:
@@ -152,6 +159,8 @@ class FusedAdam(torch.optim.Optimizer):
                 self._launch(group, entries, step_t)
         if self._grad_sync is not None:
             self._grad_sync.wait_deferred()  # nothing of the step may outlive it un-synchronised
+            if self._sharded() and touched:
+                self._grad_sync.allgather_params()
         self._last = (touched, refreshed)
         self._publish(touched, refreshed)
         return loss

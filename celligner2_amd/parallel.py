@@ -12,8 +12,17 @@ result equals the reference's step on the GLOBAL batch:
   * use_bn: the per-column (mean, M2) partials [2,H] of every BatchNorm layer are all-gathered in the forward and
     combined by the kernel (Chan), the column sums [2,H] of its backward are SUM all-reduced -- SyncBN, so that the
     statistics are those of the global batch.
-Gradient all-reduce runs per bucket of the engine's flat gradient arena, in backward-readiness order, on a side
+The gradient exchange runs per bucket of the engine's flat gradient arena, in backward-readiness order, on a side
 stream, so the decoder-output bucket (the first 78 MB at 19k genes x 1024) overlaps the rest of the backward.
+
+Two forms of the exchange:
+  * `shard_optimizer=False`: SUM all-reduce of every bucket; every rank runs Adam on every parameter.
+  * `shard_optimizer=True`: every bucket is REDUCE-SCATTERED (rank r receives the sum of chunk r), each rank runs Adam on
+    its chunks only (1/world of the optimizer's 28 bytes per parameter), and the updated chunks of the parameters --
+    views of one flat buffer laid out like the gradient arena -- are ALL-GATHERED in place.  Same bytes on the wire as
+    the all-reduce (which is a reduce-scatter plus an all-gather), the optimizer's HBM traffic divided by the world size.
+    Adam's moments exist in full shape on every rank but are only maintained inside the rank's own chunks; gradient
+    accumulation over several backward passes is not available in this form.
 """
 from __future__ import annotations
 
@@ -22,11 +31,12 @@ import torch.distributed as dist
 
 
 class DataParallelStep:
-    def __init__(self, group=None):
+    def __init__(self, group=None, shard_optimizer=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self._setup(dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group) != "nccl")
+        self.sharded = bool(shard_optimizer) and self.world_size > 1
 
     def _setup(self, world_size, rank, host_backend):
         self.world_size, self.rank = world_size, rank
@@ -38,6 +48,8 @@ class DataParallelStep:
         self._pending = []
         self.defer_last = False  # set by the optimizer wiring: the last bucket's wait moves into FusedAdam.step
         self._deferred = None    # (event, first byte, one-past-last byte) of the bucket still being reduced
+        self.sharded = False
+        self._arena = None       # (gradient arena, flat parameter buffer, buckets) of the attached engine (sharded form)
 
     # -- wiring
     def attach_model(self, model):
@@ -66,6 +78,67 @@ class DataParallelStep:
         out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
+
+    def _reduce_scatter_(self, flat):
+        """In place: chunk `rank` of `flat` (world_size equal chunks) becomes the SUM over ranks of that chunk; the other
+        chunks are left undefined.  ncclReduceScatter's in-place form (recvbuff = sendbuff + rank * recvcount)."""
+        n = flat.numel() // self.world_size
+        dist.reduce_scatter_tensor(flat[self.rank * n:(self.rank + 1) * n], flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather_(self, flat):
+        """In place: every rank's chunk `rank` of `flat` is distributed to all (ncclAllGather's in-place form)."""
+        n = flat.numel() // self.world_size
+        dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
+
+    # -- the sharded form: arena bookkeeping
+    def set_arena(self, grad_flat, param_flat, buckets):
+        for lo, hi in buckets:
+            assert (hi - lo) % (64 * self.world_size) == 0, "bucket does not cut into aligned chunks"
+        self._arena = (grad_flat, param_flat, [(lo, hi) for lo, hi in buckets if hi > lo])
+
+    def owned_ranges(self):
+        """Byte-address ranges of the gradient arena this rank owns (one chunk per bucket)."""
+        grad_flat, _, buckets = self._arena
+        base = grad_flat.data_ptr()
+        out = []
+        for lo, hi in buckets:
+            n = (hi - lo) // self.world_size
+            out.append((base + 4 * (lo + self.rank * n), base + 4 * (lo + (self.rank + 1) * n)))
+        return out
+
+    def owned_parts(self, entries):
+        """Adam entries (p, g, m, v, shadow) cut down to the elements whose gradient lies in this rank's chunks."""
+        if self._arena is None:
+            raise RuntimeError("sharded optimizer step before any backward pass built the gradient arena")
+        grad_flat = self._arena[0]
+        a_lo, a_hi = grad_flat.data_ptr(), grad_flat.data_ptr() + 4 * grad_flat.numel()
+        owned = self.owned_ranges()
+        out = []
+        for p, g, m, v, _ in entries:
+            g0 = g.data_ptr()
+            if not (a_lo <= g0 < a_hi):
+                raise NotImplementedError(
+                    "shard_optimizer=True needs every .grad to be the engine's arena view (zero_grad(set_to_none=True), "
+                    "one backward per step): accumulated copies hold un-reduced chunks")
+            g1 = g0 + 4 * g.numel()
+            for lo, hi in owned:
+                s, e = max(g0, lo), min(g1, hi)
+                if s < e:
+                    i0, i1 = (s - g0) // 4, (e - g0) // 4
+                    out.append((p.view(-1)[i0:i1], g.view(-1)[i0:i1], m.view(-1)[i0:i1], v.view(-1)[i0:i1], None))
+        return out
+
+    def allgather_params(self):
+        """After the sharded Adam: every bucket of the flat parameter buffer is completed from the ranks' chunks
+        (stream-ordered on the compute stream: the next forward reads the parameters)."""
+        _, param_flat, buckets = self._arena
+        for lo, hi in buckets:
+            seg = param_flat[lo:hi]
+            if self._host_backend:  # (gloo: no in-place form; through a host copy, as the other rehearsal exchanges)
+                n = (hi - lo) // self.world_size
+                seg.copy_(self._gather0(seg[self.rank * n:(self.rank + 1) * n].cpu()).to(seg.device))
+            else:
+                self._all_gather_(seg)
 
     # -- forward collectives
     def allgather_rows(self, feat, cond):
@@ -97,8 +170,15 @@ class DataParallelStep:
         return t
 
     # -- backward collectives
-    def allreduce_bucket_async(self, flat):
-        """SUM all-reduce of one gradient bucket on a side stream, ordered after the work already queued."""
+    def reduce_bucket_async(self, flat):
+        """The exchange of one gradient bucket: all-reduce, or reduce-scatter in the sharded form."""
+        self.allreduce_bucket_async(flat, self._reduce_scatter_ if self.sharded else None)
+
+    def allreduce_bucket_async(self, flat, collective=None):
+        """SUM all-reduce (or `collective`) of one gradient bucket on a side stream, ordered after the work already
+        queued.  (gloo rehearsals: the blocking host all-reduce serves both forms -- a reduce-scatter's result is a part
+        of it.)"""
+        collective = collective or self._sum_
         if flat.is_cuda and self._host_backend:
             self._host_reduce(flat)
         elif flat.is_cuda:
@@ -108,12 +188,12 @@ class DataParallelStep:
             ev.record(torch.cuda.current_stream(flat.device))
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                self._sum_(flat)
+                collective(flat)
                 done = torch.cuda.Event()
                 done.record(self._side)
             self._pending.append((done, flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
         else:
-            self._sum_(flat)
+            self._sum_(flat)  # (host tensors: CPU tests)
 
     def wait_all(self):
         """Order the compute stream after the bucket all-reduces.  With `defer_last`, the newest bucket (the encoder's

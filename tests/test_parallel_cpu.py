@@ -46,6 +46,31 @@ def _worker(rank, world, port, out):
     comm.allreduce_bucket_async(g)
     comm.wait_all()
     assert torch.equal(g, torch.arange(6, dtype=torch.float32) * 3)
+    # sharded form: bucket chunks, the Adam entries cut down to the owned elements, the parameter all-gather
+    sh = DataParallelStep(shard_optimizer=True)
+    assert sh.sharded
+    gflat = torch.zeros(64 * world * 3)
+    pflat = torch.arange(64 * world * 3, dtype=torch.float32) + 1000 * rank  # every rank "updated" its own chunk
+    buckets = [(0, 64 * world), (64 * world, 64 * world * 3)]
+    sh.set_arena(gflat, pflat, buckets)
+    own = sh.owned_ranges()
+    base = gflat.data_ptr()
+    assert own == [(base + 4 * 64 * rank, base + 4 * 64 * (rank + 1)),
+                   (base + 4 * (64 * world + 128 * rank), base + 4 * (64 * world + 128 * (rank + 1)))]
+    # a "parameter" whose gradient spans the boundary between the two ranks' chunks of bucket 0 and runs into bucket 1
+    g = gflat[40:64 * world + 30]
+    pp, mm, vv = torch.zeros(g.numel()), torch.zeros(g.numel()), torch.zeros(g.numel())
+    parts = sh.owned_parts([(pp, g, mm, vv, None)])
+    got = sorted((q[1].data_ptr() - base) // 4 for q in parts), sorted(q[1].numel() for q in parts)
+    want = {0: ([40, 128], [24, 30]), 1: ([64], [64])}[rank]  # rank 0: tail of its chunk + head of its bucket-1 chunk
+    assert got == (sorted(want[0]), sorted(want[1])), (rank, got)
+    assert all(q[0].data_ptr() - pp.data_ptr() == q[1].data_ptr() - g.data_ptr() for q in parts)
+    sh.allgather_params()
+    for lo, hi in buckets:
+        n = (hi - lo) // world
+        for r in range(world):
+            seg = pflat[lo + r * n:lo + (r + 1) * n]
+            assert torch.equal(seg, torch.arange(lo + r * n, lo + (r + 1) * n, dtype=torch.float32) + 1000 * r)
     # the decomposition identity, with the oracle as the per-rank compute
     rng = np.random.default_rng(0)
     B, G, C, P, L = 16, 40, 2, 3, 4

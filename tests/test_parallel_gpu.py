@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("variant", ["ln", "bn", "noise"])
+@pytest.mark.parametrize("variant", ["ln", "bn", "noise", "shard", "shard_bf16"])
 def test_two_ranks_equal_single_process(variant):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
