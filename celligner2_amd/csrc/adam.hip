@@ -7,7 +7,8 @@
 namespace c2 {
 
 constexpr int kMaxT = 48;
-constexpr int kElemsPerBlock = 256 * 8;
+constexpr int kIter = 4;                          // 16-byte chunks per thread and array
+constexpr int kElemsPerBlock = 256 * 4 * kIter;
 
 struct AdamTable {
     c2_adam_tensor t[kMaxT];
@@ -26,6 +27,23 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     v = h.beta2 * v + h.omb2 * g * g;
     const float denom = sqrtf(v) * h.inv_bc2_sqrt + h.eps;
     p = p - h.step_size * (m / denom);
+}
+
+// operand copies the GEMMs read: bf16(p), and bf16(p - bf16(p)) for the narrow layers' planes
+__device__ __forceinline__ void store_shadows(const c2_adam_tensor& t, int64_t i, const f32x4& p) {
+    u32x2 pk;
+    pk[0] = (unsigned)f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
+    pk[1] = (unsigned)f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
+    if (t.shadow_lo) {
+        bf16_t l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = f2bf(p[e] - bf2f(f2bf(p[e])));
+        u32x2 pl;
+        pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+        pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_lo) + i) = pl;
+    }
 }
 
 // Step state on the device (c2_adam_state of c2mi.h): one thread advances the step count and turns the hyper-parameters
@@ -63,8 +81,36 @@ __device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper
                        reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0 &&
                      (!t.shadow_bf16 || (reinterpret_cast<uintptr_t>(t.shadow_bf16) & 7) == 0) &&
                      (!t.shadow_lo || (reinterpret_cast<uintptr_t>(t.shadow_lo) & 7) == 0);
+    // All of the block's loads are issued before the first store: p, g, m and v come through pointers the compiler must
+    // assume to alias, so a load placed after a store in the source stays after it -- with load / update / store per
+    // chunk only four 16-byte loads per thread were ever in flight.
+    if (vec && base + kElemsPerBlock <= t.n) {
+        f32x4 p[kIter], g[kIter], m[kIter], v[kIter];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kIter; ++k) {
+            const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
+            p[k] = *reinterpret_cast<const f32x4*>(t.p + i);
+            g[k] = *reinterpret_cast<const f32x4*>(t.g + i);
+            m[k] = *reinterpret_cast<const f32x4*>(t.m + i);
+            v[k] = *reinterpret_cast<const f32x4*>(t.v + i);
+        }
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) {
+            const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = p[k][e], me = m[k][e], ve = v[k][e];
+                adam_one(pe, g[k][e], me, ve, h);
+                p[k][e] = pe; m[k][e] = me; v[k][e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(t.p + i) = p[k];
+            *reinterpret_cast<f32x4*>(t.m + i) = m[k];
+            *reinterpret_cast<f32x4*>(t.v + i) = v[k];
+            if (t.shadow_bf16) store_shadows(t, i, p[k]);
+        }
+        return;
+    }
+    for (int k = 0; k < kIter; ++k) {  // a tensor's last block, unaligned tensors
         const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
         if (i >= t.n) continue;
         if (vec && i + 4 <= t.n) {
@@ -81,21 +127,7 @@ __device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper
             *reinterpret_cast<f32x4*>(t.p + i) = p;
             *reinterpret_cast<f32x4*>(t.m + i) = m;
             *reinterpret_cast<f32x4*>(t.v + i) = v;
-            if (t.shadow_bf16) {
-                u32x2 pk;
-                pk[0] = (unsigned)f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
-                pk[1] = (unsigned)f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
-                if (t.shadow_lo) {
-                    bf16_t l[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = f2bf(p[e] - bf2f(f2bf(p[e])));
-                    u32x2 pl;
-                    pl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16);
-                    pl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_lo) + i) = pl;
-                }
-            }
+            if (t.shadow_bf16) store_shadows(t, i, p);
         } else {
             for (int e = 0; e < 4 && i + e < t.n; ++e) {
                 float pe = t.p[i + e], me = t.m[i + e], ve = t.v[i + e];

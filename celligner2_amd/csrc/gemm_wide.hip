@@ -85,11 +85,17 @@ __device__ __forceinline__ int stage_k(int j, int wave, int lane) {
     return (64 / LPR) * i + lane / LPR;
 }
 
+// `wave` must be wave-uniform in the compiler's eyes (v_readfirstlane once per kernel): the LDS destination then
+// reaches m0 through scalar arithmetic instead of a v_readfirstlane per instruction.  The source address is formed
+// as (uniform base) + zext(32-bit per-lane BYTE offset), the shape the backend turns into the scalar-base form of the
+// instruction (global_load_lds_dwordx4 v_off, s[base:base+1]) -- no 64-bit vector add per instruction.
 template <int J0, int J1>
 __device__ __forceinline__ void stage_dma(const bf16_t* base, const int (&voff)[4], char* tile, int wave) {
+    const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
     for (int j = J0; j < J1; ++j)
-        __builtin_amdgcn_global_load_lds((g_void*)(base + voff[j]), (lds_void*)(tile + (4 * wave + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_void*)(b + (uint64_t)((uint32_t)voff[j] * 2u)),
+                                         (lds_void*)(tile + (4 * wave + j) * 1024), 16, 0, 0);
 }
 
 // Last, partial K-tile: same image through registers, reduction indices >= kvalid are zero.
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     constexpr int TILE_BYTES = BX * BK * 2; // one operand tile = one ring slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // the same number, known to be wave-uniform
     const int wm = wave / WN, wn = wave % WN;
 #if C2_GEMM_DBG & 16
     const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
@@ -324,7 +331,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     }
     // IDX 2: vob[j] = rows[k-row] * ldb + xob[j]; the DMA instruction j of this wave covers k-rows 8*wave + 2j + {0,1}
     int xob[4];
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int kr[8];  // the wave's eight row indices of the B tile that is issued next
     auto load_krows = [&](int t) {
         const int32_t* rp = a.rows + rbeg + t * BK + 8 * wave_u;  // wave-uniform address: scalar loads
@@ -384,8 +390,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         if ((dbg & 1) || segA >= nseg) return;
         char* dst = smem + slot * TILE_BYTES;
         if (tA < nfull) {
-            if (q != 1) stage_dma<0, 2>(pA, voa, dst, wave);
-            if (q != 0) stage_dma<2, 4>(pA, voa, dst, wave);
+            if (q != 1) stage_dma<0, 2>(pA, voa, dst, wave_u);
+            if (q != 0) stage_dma<2, 4>(pA, voa, dst, wave_u);
         } else if (q <= 0) {
             stage_tail<A_RC, BX>(pA, voa, dst, wave, lane, ktail);
         }
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         }
         char* dst = smem + slot * TILE_BYTES;
         if (tB < nfull) {
-            if (q != 1) stage_dma<0, 2>(pB, vob, dst, wave);
-            if (q != 0) stage_dma<2, 4>(pB, vob, dst, wave);
+            if (q != 1) stage_dma<0, 2>(pB, vob, dst, wave_u);
+            if (q != 0) stage_dma<2, 4>(pB, vob, dst, wave_u);
         } else if (q <= 0) {
             stage_tail<B_RC, BX>(pB, vob, dst, wave, lane, ktail);
         }
@@ -452,10 +458,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         char* d4 = smem + slot_of(2 * D) * TILE_BYTES;      // its reads of them
         auto piece = [&](int p) {
             if (dbg & 1) return;
-            if (p == 0 && !(dbg & 8)) stage_dma<0, 2>(pB, vob, d3, wave);
-            if (p == 1 && !(dbg & 8)) stage_dma<2, 4>(pB, vob, d3, wave);
-            if (p == 2 && !(dbg & 4)) stage_dma<0, 2>(pA, voa, d4, wave);
-            if (p == 3 && !(dbg & 4)) stage_dma<2, 4>(pA, voa, d4, wave);
+            if (p == 0 && !(dbg & 8)) stage_dma<0, 2>(pB, vob, d3, wave_u);
+            if (p == 1 && !(dbg & 8)) stage_dma<2, 4>(pB, vob, d3, wave_u);
+            if (p == 2 && !(dbg & 4)) stage_dma<0, 2>(pA, voa, d4, wave_u);
+            if (p == 3 && !(dbg & 4)) stage_dma<2, 4>(pA, voa, d4, wave_u);
         };
         if (!(dbg & 2)) {
             if constexpr (M16)
@@ -581,6 +587,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
     constexpr int TILE_BYTES = BX * BK * 2;  // 16 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WN, wn = wave % WN;
     int wg;
     {
@@ -635,10 +642,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
     auto issue = [&](int t, int s) {
         char* d = smem + 4 * s * TILE_BYTES;
         if (t < nfull) {
-            stage_dma<0, 4>(pAh, voa, d, wave);
-            stage_dma<0, 4>(pBh, vob, d + TILE_BYTES, wave);
-            stage_dma<0, 4>(pAl, voa, d + 2 * TILE_BYTES, wave);
-            stage_dma<0, 4>(pBl, vob, d + 3 * TILE_BYTES, wave);
+            stage_dma<0, 4>(pAh, voa, d, wave_u);
+            stage_dma<0, 4>(pBh, vob, d + TILE_BYTES, wave_u);
+            stage_dma<0, 4>(pAl, voa, d + 2 * TILE_BYTES, wave_u);
+            stage_dma<0, 4>(pBl, vob, d + 3 * TILE_BYTES, wave_u);
         } else {  // the partial last tile: through registers, zero filled
             stage_tail<A_RC, BX>(pAh, voa, d, wave, lane, ktail);
             stage_tail<B_RC, BX>(pBh, vob, d + TILE_BYTES, wave, lane, ktail);

@@ -11,6 +11,7 @@
 // the local rows' full gradient needs only their own row block, so no backward collective exists.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace c2 {
 
@@ -144,6 +145,106 @@ __global__ __launch_bounds__(1024) void partition_kernel(const int64_t* __restri
     if (tid == 0) {
         const int np = s_nparts;
         auto add_pair = [&](int i, int j) {  // accumulated in LDS: a chain of global read-modify-writes costs ~1 us each
+            const float ni = (float)s_cnt[i], nj = (float)s_cnt[j];
+            s_wt[i * MAXP + i] += 1.f / (ni * ni);
+            s_wt[j * MAXP + j] += 1.f / (nj * nj);
+            s_wt[i * MAXP + j] -= 1.f / (ni * nj);
+            s_wt[j * MAXP + i] -= 1.f / (ni * nj);
+        };
+        if (boundary >= 0) {  // losses.py:232-238
+            for (int i = 0; i < boundary; ++i)
+                for (int j = boundary; j < n_conditions; ++j) {
+                    if (i >= np || j >= np) { s_bad = 1; continue; }  // IndexError in the reference
+                    if (s_cnt[i] < 2 || s_cnt[j] < 2) continue;
+                    add_pair(i, j);
+                }
+        } else {  // losses.py:240-248
+            for (int i = 0; i < np; ++i) {
+                if (s_cnt[i] < 1) continue;
+                for (int j = 0; j < i; ++j) {
+                    if (s_cnt[j] < 1) continue;
+                    if (main_col >= 0 && j != 0) continue;
+                    add_pair(i, j);
+                }
+            }
+        }
+        if (s_bad) *status = 2;
+    }
+    __syncthreads();
+    for (int i = tid; i < MAXP * MAXP; i += 1024) wt[i] = s_wt[i];
+}
+
+// The same partition for C <= 6 condition columns (at most 64 distinct rows = MAXP, every model of the reference's
+// examples): a row IS its key, so the unique rows, their order and the partition sizes fall out of a 64-entry
+// presence / count table and two wave ballots -- no repeated min-extraction over the batch, no per-row search.
+// Same outputs and status as partition_kernel (tests/test_ops_gpu.py compares both with the oracle).
+__global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __restrict__ cond, int64_t B, int C,
+                                                               int n_conditions, int main_col, int boundary,
+                                                               int32_t* __restrict__ part_id, float* __restrict__ wt,
+                                                               int32_t* __restrict__ status) {
+    __shared__ int s_keycnt[MAXP];   // rows per key
+    __shared__ int s_keypart[MAXP];  // key -> partition id
+    __shared__ int s_cnt[MAXP];      // rows per partition
+    __shared__ int s_bad, s_nparts;
+    __shared__ float s_wt[MAXP * MAXP];
+    const int tid = threadIdx.x;
+    if (tid < MAXP) { s_keycnt[tid] = 0; s_cnt[tid] = 0; s_keypart[tid] = 0; }
+    if (tid == 0) { s_bad = 0; s_nparts = 0; }
+    for (int i = tid; i < MAXP * MAXP; i += 1024) s_wt[i] = 0.f;
+    __syncthreads();
+    int bad = 0;
+    auto make_key = [&](int64_t r) {
+        int k = 0;
+        for (int j = 0; j < C; ++j) {
+            const int64_t v = cond[r * C + j];
+            bad |= (v != 0 && v != 1);
+            k = (k << 1) | (int)(v == 1);  // column 0 most significant: numeric order == lexicographic row order
+        }
+        return k;
+    };
+    for (int64_t r0 = 0; r0 < B; r0 += 1024) {
+        const int64_t r = r0 + tid;
+        const int k = r < B ? make_key(r) : -1;
+        // one LDS atomic per wave and key present in it (leader = lowest lane holding the key)
+        unsigned long long todo = __ballot(k >= 0);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int kl = __shfl(k, lead, 64);
+            const unsigned long long same = __ballot(k == kl);
+            if ((tid & 63) == lead) atomicAdd(&s_keycnt[kl], __popcll(same));
+            todo &= ~same;
+        }
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (tid < 64) {  // wave 0: lane = key
+        const int cnt = s_keycnt[tid];
+        const bool present = cnt > 0;
+        const unsigned long long below = (1ull << tid) - 1ull;
+        int p = 0;
+        int np;
+        if (main_col >= 0) {  // partition order: [cat(main rows)] + the rest ascending (_utils.py:31-36)
+            const bool is_main = present && ((tid >> (C - 1 - main_col)) & 1);
+            const unsigned long long bal_main = __ballot(is_main), bal_rest = __ballot(present && !is_main);
+            if (!bal_main && tid == 0) s_bad = 1;  // torch.cat([]) raises in the reference
+            p = is_main ? 0 : 1 + __popcll(bal_rest & below);
+            np = 1 + __popcll(bal_rest);
+        } else {
+            const unsigned long long bal = __ballot(present);
+            p = __popcll(bal & below);
+            np = __popcll(bal);
+        }
+        if (present) {
+            s_keypart[tid] = p;
+            atomicAdd(&s_cnt[p], cnt);
+        }
+        if (tid == 0) s_nparts = np;
+    }
+    __syncthreads();
+    for (int64_t r = tid; r < B; r += 1024) part_id[r] = s_keypart[make_key(r)];
+    if (tid == 0) {
+        const int np = s_nparts;
+        auto add_pair = [&](int i, int j) {
             const float ni = (float)s_cnt[i], nj = (float)s_cnt[j];
             s_wt[i * MAXP + i] += 1.f / (ni * ni);
             s_wt[j * MAXP + j] += 1.f / (nj * nj);
@@ -719,8 +820,13 @@ extern "C" int c2_partition(const int64_t* cond, int64_t B, int C, int n_conditi
     C2_CHECK(C >= 1 && C <= 64, "MMD partition supports 1..64 condition columns");
     C2_CHECK(main_col < C, "main_col out of range");
     C2_CHECK(B >= 1, "empty batch");
-    hipLaunchKernelGGL(partition_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cond, B, C, n_conditions,
-                       main_col, boundary, part_id, wt, (unsigned long long*)ws, status_dev);
+    static const bool general_only = getenv("C2_PARTITION_GENERAL") != nullptr;  // A/B and tests: the general kernel
+    if (C <= 6 && !general_only)  // at most 2^6 = MAXP distinct rows: the table form
+        hipLaunchKernelGGL(partition_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cond, B, C, n_conditions,
+                           main_col, boundary, part_id, wt, status_dev);
+    else
+        hipLaunchKernelGGL(partition_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cond, B, C, n_conditions,
+                           main_col, boundary, part_id, wt, (unsigned long long*)ws, status_dev);
     C2_LAUNCH_CHECK();
     return 0;
 }

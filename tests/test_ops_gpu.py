@@ -452,7 +452,11 @@ def test_classifier_loss(P):
 
 @pytest.mark.parametrize("B,D,C,main,boundary,multi", [(64, 10, 3, None, None, False), (200, 64, 5, 1, None, False),
                                                        (96, 5, 4, None, 2, True), (150, 100, 2, None, None, False),
-                                                       (33, 16, 3, 0, None, True)])
+                                                       (33, 16, 3, 0, None, True),
+                                                       # more than one pass of the 1024-thread block over the rows
+                                                       (5000, 8, 3, None, None, False), (2500, 8, 6, 0, None, True),
+                                                       # C > 6: the general (sorting) partition kernel
+                                                       (300, 8, 7, None, None, True), (260, 12, 9, 2, None, False)])
 def test_partition_and_mmd(B, D, C, main, boundary, multi):
     ops = _ops()
     rng = np.random.default_rng(B + D)
@@ -497,7 +501,7 @@ def test_partition_and_mmd(B, D, C, main, boundary, multi):
 def test_adam_matches_oracle():
     ops = _ops()
     rng = np.random.default_rng(9)
-    shapes = [(19, 7), (1000,), (33, 128), (5,)]
+    shapes = [(19, 7), (1000,), (33, 128), (5,), (5000, 3), (4096,), (3, 4099)]  # whole blocks (4096) and tails
     params = {f"p{i}": rng.standard_normal(s).astype(np.float32) for i, s in enumerate(shapes)}
     tp = {k: T(v.copy()) for k, v in params.items()}
     tm = {k: torch.zeros_like(v) for k, v in tp.items()}
