@@ -750,8 +750,12 @@ int wide_tile(int dtype, const GemmArgs& a) {
         return (a.R >= 64 && a.M >= 1 && a.N >= 1) ? 128 : 0;
     }
     // worth a 256x256 tile: a gene-width problem
-    if ((int64_t)a.M * a.N < 256ll * 256 * 32 || a.R < 256 || a.M < 192 || a.N < 192) return 0;
-    return 256;
+    if ((int64_t)a.M * a.N >= 256ll * 256 * 32 && a.R >= 256 && a.M >= 192 && a.N >= 192) return 256;
+    // short-and-wide bf16 problems (the gene-width layers at the reference's default batch of 128): the 128x128
+    // LDS-DMA instance instead of the register-staged kernel (C2_GEMM_BF16_128=0: A/B)
+    static const bool small_on = []() { const char* e = getenv("C2_GEMM_BF16_128"); return !(e && e[0] == '0'); }();
+    if (small_on && a.R >= 128 && (int64_t)a.M * a.N >= 128ll * 128 * 2) return 128;
+    return 0;
 }
 
 template <int NW>

@@ -87,6 +87,8 @@ def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False
     target = 256 if (tile == 256 or planes) else 512
     if tiles >= target or R <= 4 * bk:
         return 1
+    if tiles <= 4 and dtype == torch.bfloat16:
+        max_slab = max(max_slab, 64)  # a gene-width reduction into a one-batch-of-128 output: 4 tiles x 64 slabs fill the chip
     n = min(max_slab, (target + tiles - 1) // tiles, max(1, R // (4 * bk)))
     return max(1, n)
 
