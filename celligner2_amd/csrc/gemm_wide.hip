@@ -47,12 +47,19 @@ typedef __attribute__((address_space(1))) const void g_void;
 // Per-lane source offset (elements, relative to the tile's first row / column at reduction index 0) of LDS-DMA
 // instruction i = 4*wave + j of one operand tile of BX rows (RC) / BX columns (XC).  Instruction i writes LDS bytes
 // [1024*i, 1024*i + 1024), lane l the 16 B at 1024*i + 16*l.
-// XOR applied to the 64-byte granule index of k-row k in an XC image.  Bits 0-1 = k & 3: the 4 k-rows of one transposing
-// read fall in 4 different granules.  BX = 256 (8 granules per k-row) adds bit 2 = (k >> 3) & 1: the two 16-lane groups
-// of a 32-lane half of the 16x16x32 operand read k-rows 8 apart in the same columns (4 KB apart = the same banks).
+// XC image, k-row k: the 64-byte granule index is XORed with k & 3 (the 4 k-rows of one transposing read fall in 4
+// different granules = 4 different quarters of the 256-byte bank row), and for BX = 256 the two 32-byte halves of every
+// granule are swapped when (k >> 3) & 1: a 32-lane half of the 16x16x32 operand reads, in the same columns, four
+// k-rows and the four k-rows 8 further on -- 4 KB apart, i.e. on the same banks (measured: SQ_LDS_BANK_CONFLICT = 26 % of
+// the LDS cycles of the dgrad kernel); with the swap they take the other half of each quarter.  The 32x32x16 read's
+// 32-lane halves stay inside one value of (k >> 3) & 1 and remain conflict-free.
 template <int BX>
 __device__ __forceinline__ int xc_swz(int k) {
-    return BX == 256 ? ((k & 3) | (((k >> 3) & 1) << 2)) : (k & 3);
+    return k & 3;
+}
+template <int BX>
+__device__ __forceinline__ int xc_half(int k) {
+    return BX == 256 ? ((k >> 3) & 1) : 0;
 }
 
 template <bool RC, int BX>
@@ -66,7 +73,7 @@ __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot,
     } else {
         constexpr int LPR = BX / 8;  // lanes (16-byte chunks) per k-row
         const int k = (64 / LPR) * i + lane / LPR, p = lane % LPR;
-        const int ch = (((p >> 2) ^ xc_swz<BX>(k)) << 2) | (p & 3);
+        const int ch = (((p >> 2) ^ xc_swz<BX>(k)) << 2) | ((p & 3) ^ (xc_half<BX>(k) << 1));
         int x = ch * 8;
         if (x0 + x >= xtot) x = 0;  // chunk entirely past the edge: any valid address (outputs discarded)
         return k * (int)ld + x;
@@ -123,7 +130,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int xt, int ks, in
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3, h = lane >> 5;
         const int k = 16 * ks + 8 * h + q;
         const int xb = (xt + 16 * (g & 1) + 4 * p4) * 2;
-        const int off = k * RB + ((((xb >> 6) ^ xc_swz<BX>(k)) & (RB / 64 - 1)) << 6) + (xb & 63);
+        const int off = k * RB + ((((xb >> 6) ^ xc_swz<BX>(k)) & (RB / 64 - 1)) << 6) + ((xb & 63) ^ (xc_half<BX>(k) << 5));
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * RB));  // (k + 4: same swizzle)
@@ -192,7 +199,7 @@ __device__ __forceinline__ bf16x8 read_frag16(const char* tile, int xt, int ks, 
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3;
         const int k = 32 * ks + 8 * g + q;
         const int xb = (xt + 4 * p4) * 2;
-        const int off = k * RB + ((((xb >> 6) ^ xc_swz<BX>(k)) & (RB / 64 - 1)) << 6) + (xb & 63);
+        const int off = k * RB + ((((xb >> 6) ^ xc_swz<BX>(k)) & (RB / 64 - 1)) << 6) + ((xb & 63) ^ (xc_half<BX>(k) << 5));
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * RB));
