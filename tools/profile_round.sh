@@ -15,7 +15,7 @@ for cfg in c4 c2; do
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/trace_$cfg -- python3 $root/bench.py --profile-pass --config $cfg --steps $steps --warmup $warm > $out/trace_$cfg.log 2>&1 || exit 3
   db=$(find $out/trace_$cfg -name "*.db" | head -1)
   python3 $root/tools/rocpd_stats.py $db > $out/${cfg}_kernel_stats.txt || exit 4
-  echo "# python3 bench.py --profile-pass --config $cfg --steps $steps --warmup $warm  (rocprofv3 --kernel-trace --stats; $((steps + warm)) steps + capture)" >> $out/${cfg}_kernel_stats.txt
+  echo "# python3 bench.py --profile-pass --config $cfg --steps $steps --warmup $warm  (rocprofv3 --kernel-trace --stats, summarised by tools/rocpd_stats.py; $((steps + warm + 3)) steps: 3 set-up steps -- two launched kernel by kernel, then the one that captures the graph -- + $warm warm-up + $steps timed replays; the poisson / compare / reduce kernels at the top build the synthetic dataset)" >> $out/${cfg}_kernel_stats.txt
   rm -rf $out/trace_$cfg
 done
 cd $root
