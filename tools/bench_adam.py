@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from celligner2_amd import ops
 n = 19000 * 1024
 ts = []
