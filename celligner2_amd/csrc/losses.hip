@@ -63,8 +63,21 @@ __device__ __forceinline__ float digamma_pos(float z) {
 // past the last gene without a bounds test.
 __host__ __device__ inline int64_t nb_tab_ld(int64_t G) { return (G + 12287) / 12288 * 12288; }
 
-__global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab) {
+// The same launch also classifies the batch's condition rows for the fast loss kernel (rowflags[b]: 1 = the row holds a 0,
+// 2 = it holds a 1, 4 = an entry outside {0,1} or >= C), so that the loss kernel fetches ONE word per row, a row ahead.
+__global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab,
+                                const int64_t* __restrict__ cond, int64_t B, int* __restrict__ rowflags) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (rowflags) {
+        for (int64_t r = g; r < B; r += (int64_t)gridDim.x * blockDim.x) {
+            int f = 0;
+            for (int j = 0; j < C; ++j) {
+                const int64_t v = cond[r * C + j];
+                f |= (v == 0 ? 1 : 0) | (v == 1 ? 2 : 0) | (((v < 0) | (v > 1) | (v >= C)) ? 4 : 0);
+            }
+            rowflags[r] = f;
+        }
+    }
     if (g >= Gp) return;
     if (g >= G) {
 #pragma unroll
@@ -105,6 +118,7 @@ struct NbArgs {
     int64_t ldl, ldx, ldg, lddl, B, G;
     int C;
     float inv_B;
+    const int* rowflags;  // [B] classification of the condition rows (nb_table_kernel); the fast NB kernel only
 };
 
 // fast transcendental forms: every argument here is a normal positive float (>= 1e-8)
@@ -438,56 +452,77 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     auto load_m = [&](int i, __amdgpu_buffer_rsrc_t rg) {
         return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, tid * 4, i * NT * 4, 0);
     };
-    int64_t pref_row = -1;
     // `4 * (tid + NT * i) < always`: true for every lane and chunk, but not to the compiler (it does not know G >= 0): a
     // real branch around each chunk's (and each gene pair's) body keeps its temporaries and loads from being
     // interleaved with the others' (as straight-line code the register allocator spilled 300 registers)
     const int always = Gi + 4 * NT * NV + 8;
+    // The FIRST row's logits and its first two chunks of counts / mask are requested here exactly as every later row's
+    // are requested by the row before it (into nx and into the rolling slots chunk NV + k would take), and waited for:
+    // the loop then has ONE way of reaching a row.  With a second, load-it-now path inside the loop the compiler sized
+    // the counted vmcnt waits at the head of a row for that path (where the logits are the newest loads), which on the
+    // prefetched path made every row wait out the stores and prefetches issued just before it (~25 % of the kernel).
+    if ((int64_t)blockIdx.x < a.B) {
+        const int64_t row = blockIdx.x;
+        const int64_t srow = a.ridx ? a.ridx[row] : row;
+        const auto rx = row_rsrc(a.x + srow * a.ldx, Gi * 4);
+        const auto rg = row_rsrc(a.goodloc + srow * a.ldg, Gi);
+        const auto rl = row_rsrc(a.logits + row * a.ldl, Gi * 4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) nx[i] = load_o(i, rl);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { xq[(NV + k) % 3] = load_x(k, rx); mq[(NV + k) % 3] = load_m(k, rg); }
+    }
+    // The per-row scalars -- condition pattern, source row, size factor, data-only term -- are fetched one row ahead too:
+    // loaded at the head of the row that uses them they are the NEWEST loads, and the wait for the newest load is a full
+    // drain of the stores and prefetches issued just before it.
+    struct RowMeta { int flags; int srow; float sf, lgx; };  // flags: 1 = a 0 entry, 2 = a 1 entry, 4 = out of {0,1}
+    auto load_meta = [&](int64_t r) {
+        RowMeta m{0, 0, 0.f, 0.f};
+        if (r < a.B) {
+            // Read through the constant address space: wave-uniform addresses then become SCALAR loads (written by
+            // earlier kernels, read-only here), which land in scalar registers on their own counter -- a vector load
+            // of a uniform value is moved to a scalar register at once, i.e. waited for where it is issued.
+            typedef const __attribute__((address_space(4))) int* cint_p;
+            typedef const __attribute__((address_space(4))) int64_t* clong_p;
+            typedef const __attribute__((address_space(4))) float* cfloat_p;
+            m.flags = ((cint_p)a.rowflags)[r];
+            m.srow = (int)(a.ridx ? ((clong_p)a.ridx)[r] : r);
+            m.sf = ((cfloat_p)a.sizefactor)[r];
+            m.lgx = HAS_LGX ? ((cfloat_p)a.lgx)[r] : 0.f;
+        }
+        return m;
+    };
+    RowMeta nmeta = load_meta(blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
-        int has0 = 0, has1 = 0, bad = 0;
-        for (int j = 0; j < a.C; ++j) {
-            const int64_t v = a.cond[row * a.C + j];
-            has0 |= (v == 0);
-            has1 |= (v == 1);
-            bad |= (v < 0) | (v > 1) | (v >= a.C);
-        }
-        if (bad || (!has0 && !has1)) {
-            if (tid == 0) *a.status = 1;
-            continue;
-        }
+        const RowMeta meta = nmeta;
+        nmeta = load_meta(row + gridDim.x);  // in flight for the whole of this row
+        const int has0 = meta.flags & 1, has1 = meta.flags & 2, bad = meta.flags & 4;
+        // a row the reference would raise on: flagged, then processed like any other (its numbers are not used -- the
+        // host raises when it reads the status word) so that the prefetch chain is not broken
+        if ((bad || (!has0 && !has1)) && tid == 0) *a.status = 1;
         const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
         if (pat != cur_pat) {
             if (cur_pat >= 0) flush(cur_pat);
             cur_pat = pat;
         }
-        if (pref_row != row) {
-            const int64_t srow = a.ridx ? a.ridx[row] : row;
-            const auto rx = row_rsrc(a.x + srow * a.ldx, Gi * 4);
-            const auto rg = row_rsrc(a.goodloc + srow * a.ldg, Gi);
-            const auto rl = row_rsrc(a.logits + row * a.ldl, Gi * 4);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) ev[i] = load_o(i, rl);
-#pragma unroll
-            for (int i = 0; i < 2 && i < NV; ++i) { xq[i] = load_x(i, rx); mq[i] = load_m(i, rg); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) ev[i] = nx[i];
-            // the previous row's last two chunks requested this row's chunks 0 and 1 into the slots they had free
-            // (chunk NV + k lands in slot (NV + k) % 3): rotate them to slots 0 and 1
-            if (NV % 3 == 1) { const f32x4 t = xq[1]; const unsigned u = mq[1]; xq[1] = xq[2]; mq[1] = mq[2]; xq[0] = t; mq[0] = u; }
-            if (NV % 3 == 2) { const f32x4 t = xq[2]; const unsigned u = mq[2]; xq[1] = xq[0]; mq[1] = mq[0]; xq[0] = t; mq[0] = u; }
-        }
-        const int64_t srow_c = a.ridx ? a.ridx[row] : row;
+        for (int i = 0; i < NV; ++i) ev[i] = nx[i];
+        const bool rotate = true;
+        const int64_t srow_c = meta.srow;
         const auto rxc = row_rsrc(a.x + srow_c * a.ldx, Gi * 4);
         const auto rgc = row_rsrc(a.goodloc + srow_c * a.ldg, Gi);
         const int64_t nrow = row + gridDim.x;  // next row of this workgroup (for the prefetch)
         const bool has_next = nrow < a.B;
-        const int64_t nsrow = has_next ? (a.ridx ? a.ridx[nrow] : nrow) : 0;
+        // (the last row of a workgroup "prefetches" itself again: every row then issues the same memory operations in
+        // the same order, which is what lets the compiler count its vmcnt waits exactly -- with a shorter last-row path
+        // merged in, the waits of the final chunks of EVERY row were full drains)
+        const int64_t nsrow = has_next ? nmeta.srow : srow_c;
         const auto nrl = row_rsrc(a.logits + (has_next ? nrow : row) * a.ldl, Gi * 4);
         const auto nrx = row_rsrc(a.x + nsrow * a.ldx, Gi * 4);
         const auto nrg = row_rsrc(a.goodloc + nsrow * a.ldg, Gi);
-        const float sf = a.sizefactor[row];
-        const float lgx_row = HAS_LGX ? a.lgx[row] : 0.f;
+        const float sf = meta.sf;
+        const float lgx_row = meta.lgx;
         const int64_t Gp = nb_tab_ld(G);
         const float* tth = a.tab + (int64_t)(pat * 3 + 0) * Gp + 4 * tid;
         const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * Gp + 4 * tid;
@@ -511,10 +546,9 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         sm = block_sum<NT>(sm, red);
         const float inv_sum = 1.0f / sm;
         const f32x2 cmu = v2(sf * inv_sum), eps2 = v2(1e-8f);
-        if (has_next) {  // a whole row of arithmetic lies ahead: request the next row's logits now
+        // a whole row of arithmetic lies ahead: request the next row's logits now
 #pragma unroll
-            for (int i = 0; i < NV; ++i) nx[i] = load_o(i, nrl);
-        }
+        for (int i = 0; i < NV; ++i) nx[i] = load_o(i, nrl);
         // ---- pass A
         f32x2 S2 = v2(0.f), L2 = v2(0.f);
         // (padded table: always in bounds; 8 bytes per lane and load, L2-resident, requested one gene pair ahead)
@@ -524,19 +558,30 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             t[2] = *reinterpret_cast<const f32x2*>(tk2 + 4 * NT * (pair >> 1) + 2 * (pair & 1));
         };
         load_tab(0, tq[0]);
+        if (rotate) {
+            // The previous row's last two chunks requested this row's chunks 0 and 1 into the slots they had free (chunk
+            // NV + k lands in slot (NV + k) % 3): rotate them to slots 0 and 1.  Done HERE and not at the head of the row:
+            // the moves need the values, and those two loads were issued just before pass B of the previous row -- at the
+            // head of the row the wave waited out their HBM round trip (phase clocks: ~20 % of the kernel).
+            if (NV % 3 == 1) { const f32x4 t = xq[1]; const unsigned u = mq[1]; xq[1] = xq[2]; mq[1] = mq[2]; xq[0] = t; mq[0] = u; }
+            if (NV % 3 == 2) { const f32x4 t = xq[2]; const unsigned u = mq[2]; xq[1] = xq[0]; mq[1] = mq[0]; xq[0] = t; mq[0] = u; }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             // this chunk's counts and mask were requested two chunks ago; request those of chunk i + 2 (of the next row
             // when this row ends) into the slot chunk i - 1 has released
             const f32x4 xcur = xq[i % 3];
             const unsigned mcur = mq[i % 3];
+            // table values of the chunk's SECOND gene pair first, the counts of chunk i + 2 after them: vmcnt counts in
+            // issue order, so a table load issued after the (HBM) count loads could only be waited for together with them
+            load_tab(2 * i + 1, tq[1]);
             if (i + 2 < NV) { xq[(i + 2) % 3] = load_x(i + 2, rxc); mq[(i + 2) % 3] = load_m(i + 2, rgc); }
-            else if (has_next) { xq[(i + 2) % 3] = load_x(i + 2 - NV, nrx); mq[(i + 2) % 3] = load_m(i + 2 - NV, nrg); }
+            else { xq[(i + 2) % 3] = load_x(i + 2 - NV, nrx); mq[(i + 2) % 3] = load_m(i + 2 - NV, nrg); }
             if (4 * (tid + NT * i) < Gi) {  // (waves wholly past the last gene skip the chunk)
                 f32x4 dt4, pg4;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) if (4 * (tid + NT * i) + 2 * h < always) {  // (its own basic block, as above)
-                    if (2 * i + h + 1 < 2 * NV) load_tab(2 * i + h + 1, tq[(h + 1) & 1]);
+                    if (h == 1 && 2 * i + 2 < 2 * NV) load_tab(2 * i + 2, tq[0]);  // first pair of the next chunk
                     // keep-mask of the two genes as 0/1 floats (0 past the last gene: the mask load returned zeros); a
                     // count under a cleared mask may hold anything (the reference zeroes ll there after the fact): it is
                     // replaced by 0 so that everything below is finite
@@ -600,7 +645,6 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             }
         }
         if (HAS_LGX && tid == 0) loss_acc -= lgx_row;
-        pref_row = has_next ? nrow : -1;
     }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
@@ -864,7 +908,8 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     (void)C;
     const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
     // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
-    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G);
+    // ... + dtheta slices + the row classification (B ints)
+    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G + B + 64);
 }
 
 template <typename TD>
@@ -933,15 +978,17 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     float* part_dt = tab + 9 * nb_tab_ld(G);
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
-    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab);
+    float* part2 = part_loss + ngroups + 32;
+    int* rowflags = reinterpret_cast<int*>(part2 + (int64_t)kDthSlices * 3 * G) + 16;
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
+                       cond, B, rowflags);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
+             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags};
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
-    float* part2 = part_loss + ngroups + 32;
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
                        ngroups, G, part2);
     hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
@@ -969,7 +1016,8 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     float* part_dt = tab + 9 * nb_tab_ld(G);
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
-    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
+                       (const int64_t*)nullptr, (int64_t)0, (int*)nullptr);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     ZinbExtra z{pi, dpi, ldpi, lddpi};
