@@ -63,10 +63,12 @@ __device__ __forceinline__ float digamma_pos(float z) {
 // past the last gene without a bounds test.
 __host__ __device__ inline int64_t nb_tab_ld(int64_t G) { return (G + 12287) / 12288 * 12288; }
 
+// `status` (may be null) is set to 2 when a dispersion exp(theta) is below 1e-17 or not a number.
 // The same launch also classifies the batch's condition rows for the fast loss kernel (rowflags[b]: 1 = the row holds a 0,
 // 2 = it holds a 1, 4 = an entry outside {0,1} or >= C), so that the loss kernel fetches ONE word per row, a row ahead.
 __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab,
-                                const int64_t* __restrict__ cond, int64_t B, int* __restrict__ rowflags) {
+                                const int64_t* __restrict__ cond, int64_t B, int* __restrict__ rowflags,
+                                int32_t* __restrict__ status, int pair_nt) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (rowflags) {
         for (int64_t r = g; r < B; r += (int64_t)gridDim.x * blockDim.x) {
@@ -79,12 +81,21 @@ __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t 
         }
     }
     if (g >= Gp) return;
+    // where gene g sits inside a plane: in gene order, or (pair_nt = the fast loss kernel's workgroup size) in the order
+    // that kernel reads it -- thread t of pair_nt owns genes 4 (t + pair_nt i) .. + 3 of chunk i and takes them as two
+    // pairs; the pairs of one (chunk, half) lie side by side, so that a wave's 8-byte loads cover whole cache lines
+    // (in gene order they took every other 8 bytes, and each line was fetched from L2 twice)
+    int64_t at = g;
+    if (pair_nt) {
+        const int64_t q = g >> 2, i = q / pair_nt, t = q - i * pair_nt;
+        at = ((i * 2 + ((g >> 1) & 1)) * pair_nt + t) * 2 + (g & 1);
+    }
     if (g >= G) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            tab[(p * 3 + 0) * Gp + g] = 1.f;
-            tab[(p * 3 + 1) * Gp + g] = 0.f;
-            tab[(p * 3 + 2) * Gp + g] = 0.f;
+            tab[(p * 3 + 0) * Gp + at] = 1.f;
+            tab[(p * 3 + 1) * Gp + at] = 0.f;
+            tab[(p * 3 + 2) * Gp + at] = 0.f;
         }
         return;
     }
@@ -95,9 +106,11 @@ __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t 
         const float t = p == 0 ? t0 : (p == 1 ? t1 : t0 + t1);
         const float th = expf(t);
         const float lte = logf(th + 1e-8f);
-        tab[(p * 3 + 0) * Gp + g] = th;
-        tab[(p * 3 + 1) * Gp + g] = th * lte - lgamma_pos(th);
-        tab[(p * 3 + 2) * Gp + g] = lte + th / (th + 1e-8f) - digamma_pos(th);
+        // the fast loss kernel's domain (nb_pair): a dispersion below 1e-17 is reported, not silently mis-evaluated
+        if (status && !(th >= 1e-17f)) *status = 2;
+        tab[(p * 3 + 0) * Gp + at] = th;
+        tab[(p * 3 + 1) * Gp + at] = th * lte - lgamma_pos(th);
+        tab[(p * 3 + 2) * Gp + at] = lte + th / (th + 1e-8f) - digamma_pos(th);
     }
 }
 
@@ -374,21 +387,53 @@ __device__ __forceinline__ f32x2 vlog(f32x2 v) {  // natural log, arguments norm
 }
 __device__ __forceinline__ f32x2 vrcp(f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
 
-// lgamma(z) and digamma(z), z > 0, by ONE upward shift of three taken unconditionally (no selects):
-//   lgamma(z) = lgamma(z+3) - log P,  digamma(z) = digamma(z+3) - P'/P,  P = z (z+1) (z+2)  (products, no cancellation)
-// and the asymptotic series at z+3 >= 3, three terms each: truncation lgamma < 1/(1680 * 3^7) = 2.7e-7,
-// digamma < 1/(240 * 3^8) = 6.4e-7 (absolute).  Four transcendentals per value: rcp, log of z+3; log, rcp of P.
-__device__ __forceinline__ void lgam_digam2(f32x2 z, f32x2& lg, f32x2& dg) {
+__device__ __forceinline__ f32x2 vlog2(f32x2 v) {  // base-2 log, arguments normal positive floats
+    return f32x2{__builtin_amdgcn_logf(v[0]), __builtin_amdgcn_logf(v[1])};
+}
+
+// The per-gene arithmetic of the fast NB kernel on a pair of genes, SIX transcendentals per gene (the exponential of
+// the softmax, two reciprocals, three logarithms) where the formulas as written take eleven:
+//   mu = e * cmu, mue = mu + eps, tm = theta + mue, z = x + theta
+//   ll         = K1 - z log tm + x log mue + lgamma(z)               (- lgamma(x+1): a constant of the data)
+//   mu dll/dmu = x mu / mue - z mu / tm  =  mu theta (x - mue) / (tm mue)        (exact algebra, no cancellation added)
+//   dll/dtheta = K2 - log tm - z / tm + digamma(z)
+// lgamma and digamma by ONE upward shift of three, taken unconditionally, and the asymptotic series at zs = z + 3 >= 3:
+//   lgamma(z) = lgamma(zs) - log P,  digamma(z) = digamma(zs) - P'/P,  P = z (z+1) (z+2)   (products: no cancellation)
+//   truncation after three terms: lgamma < 1/(1680 * 3^7) = 2.7e-7, digamma < 1/(240 * 3^8) = 6.4e-7 (absolute).
+// Reciprocals: 1/tm and 1/mue from ONE reciprocal of tm * mue, 1/zs and 1/P from one of zs * P.
+// Logarithms: only three combinations are ever needed, each the logarithm of one quotient:
+//   A = log(zs / tm)           -> dll/dtheta = K2 + A - z/tm - [digamma series] - P'/P
+//   C = log mue
+//   Bq = log(zs^5 / P^2)       -> ll = K1 + z A + x C + Bq / 2 - zs + log sqrt(2 pi) + [lgamma series]
+//   (z log tm - (zs - 1/2) log zs + log P  =  -z A - 5/2 log zs + log P, since zs - 1/2 - z = 5/2).
+// Domain: zs^5 / P^2 and 1 / (zs P) must be normal floats: 1e-18 <= x + theta <= 1e9 (nb_table_kernel raises the
+// status word for a dispersion below that; counts that large are not exact in fp32 anyway).
+struct NbPair { f32x2 ll, dmu_mu, dth; };
+__device__ __forceinline__ NbPair nb_pair(f32x2 x, f32x2 e, f32x2 th, f32x2 k1, f32x2 k2, f32x2 cmu) {
+    const f32x2 ln2 = v2(0.6931471805599453f);
+    const f32x2 mu = e * cmu;
+    const f32x2 mue = mu + v2(1e-8f);
+    const f32x2 tm = th + mue;
+    const f32x2 z = x + th;
     const f32x2 z1 = z + v2(1.f), z2 = z + v2(2.f), zs = z + v2(3.f);
     const f32x2 m12 = z1 * z2;
     const f32x2 P = z * m12;
     const f32x2 dP = z * (z1 + z2) + m12;
-    const f32x2 r = vrcp(zs), lz = vlog(zs);
+    const f32x2 R1 = vrcp(tm * mue), R2 = vrcp(zs * P);
+    const f32x2 rtm = mue * R1;       // 1 / tm
+    const f32x2 r = P * R2, rP = zs * R2;  // 1 / zs, 1 / P
+    const f32x2 A = vlog2(zs * rtm);
+    const f32x2 C = vlog2(mue);
+    const f32x2 w = (zs * zs) * rP;
+    const f32x2 Bq = vlog2((w * w) * zs);
     const f32x2 r2 = r * r;
-    lg = (zs - v2(0.5f)) * lz - zs + v2(0.918938533205f) +
-         r * (v2(0.083333333333f) + r2 * (v2(-0.002777777778f) + r2 * v2(0.000793650794f))) - vlog(P);
-    dg = lz - v2(0.5f) * r - r2 * (v2(0.083333333333f) - r2 * (v2(0.008333333333f) - r2 * v2(0.003968253968f))) -
-         dP * vrcp(P);
+    NbPair o;
+    const f32x2 lser = r * (v2(0.083333333333f) + r2 * (v2(-0.002777777778f) + r2 * v2(0.000793650794f)));
+    o.ll = (z * A + x * C + v2(0.5f) * Bq) * ln2 + ((k1 - zs) + v2(0.918938533205f) + lser);
+    o.dmu_mu = (mu * R1) * (th * (x - mue));
+    const f32x2 dser = r * (v2(0.5f) + r * (v2(0.083333333333f) - r2 * (v2(0.008333333333f) - r2 * v2(0.003968253968f))));
+    o.dth = A * ln2 + (k2 - z * rtm - dser - dP * rP);
+    return o;
 }
 
 // Fast path (16-byte aligned rows, G % 4 == 0): one workgroup walks whole rows; thread t owns columns
@@ -432,7 +477,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     f32x4 ev[NV], nx[NV];
     f32x4 xq[3];       // counts of chunks i, i+1, i+2 (slot = chunk % 3)
     unsigned mq[3];    // their masks
-    f32x2 tq[2][3];    // theta, K1, K2 of this gene pair and of the next one (slot = pair % 2)
+    f32x2 tq[3][3];    // theta, K1, K2 of this gene pair and of the next two (slot = pair % 3)
     const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     // Rows are addressed through buffer resources (base = the row, extent = its G elements): every lane of every wave
     // issues every memory operation of every chunk -- a lane past the last gene loads zeros and its store is dropped
@@ -494,6 +539,18 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     };
     RowMeta nmeta = load_meta(blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The workgroups walk rows of equal cost and would stay in step, every CU of an XCD asking for its logits, counts and
+    // stores in the same microsecond: every second one starts 2, 4 or 6 us late (same-box A/B: 277 -> 272 us).
+#ifndef C2_NB_STAGGER
+#define C2_NB_STAGGER 63
+#endif
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 3); ++k) __builtin_amdgcn_s_sleep(C2_NB_STAGGER);
+#ifdef C2_NB_DBG
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
+#define C2_PH(k) { const long long t_ = clock64(); ph[k] += t_ - tprev; tprev = t_; }
+#else
+#define C2_PH(k)
+#endif
     for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
         const RowMeta meta = nmeta;
         nmeta = load_meta(row + gridDim.x);  // in flight for the whole of this row
@@ -524,9 +581,9 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         const float sf = meta.sf;
         const float lgx_row = meta.lgx;
         const int64_t Gp = nb_tab_ld(G);
-        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * Gp + 4 * tid;
-        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * Gp + 4 * tid;
-        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * Gp + 4 * tid;
+        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * Gp + 2 * tid;  // (pair order: nb_table_kernel, pair_nt = NT)
+        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * Gp + 2 * tid;
+        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * Gp + 2 * tid;
         const float scale = -a.inv_B;
         float mx = -INFINITY;
 #pragma unroll
@@ -534,7 +591,9 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             if (4 * (tid + NT * i) >= Gi) ev[i] = ninf;  // columns past the end: exp(-inf - max) = 0
             mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
         }
+        C2_PH(0)
         mx = block_max<NT>(mx, red);
+        C2_PH(1)
         float sm = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -544,18 +603,16 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                 sm += ev[i][k];
             }
         sm = block_sum<NT>(sm, red);
+        C2_PH(2)
         const float inv_sum = 1.0f / sm;
-        const f32x2 cmu = v2(sf * inv_sum), eps2 = v2(1e-8f);
-        // a whole row of arithmetic lies ahead: request the next row's logits now
-#pragma unroll
-        for (int i = 0; i < NV; ++i) nx[i] = load_o(i, nrl);
+        const f32x2 cmu = v2(sf * inv_sum);
         // ---- pass A
         f32x2 S2 = v2(0.f), L2 = v2(0.f);
         // (padded table: always in bounds; 8 bytes per lane and load, L2-resident, requested one gene pair ahead)
         auto load_tab = [&](int pair, f32x2 (&t)[3]) {
-            t[0] = *reinterpret_cast<const f32x2*>(tth + 4 * NT * (pair >> 1) + 2 * (pair & 1));
-            t[1] = *reinterpret_cast<const f32x2*>(tk1 + 4 * NT * (pair >> 1) + 2 * (pair & 1));
-            t[2] = *reinterpret_cast<const f32x2*>(tk2 + 4 * NT * (pair >> 1) + 2 * (pair & 1));
+            t[0] = *reinterpret_cast<const f32x2*>(tth + 2 * NT * pair);
+            t[1] = *reinterpret_cast<const f32x2*>(tk1 + 2 * NT * pair);
+            t[2] = *reinterpret_cast<const f32x2*>(tk2 + 2 * NT * pair);
         };
         load_tab(0, tq[0]);
         if (rotate) {
@@ -574,14 +631,25 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             const unsigned mcur = mq[i % 3];
             // table values of the chunk's SECOND gene pair first, the counts of chunk i + 2 after them: vmcnt counts in
             // issue order, so a table load issued after the (HBM) count loads could only be waited for together with them
-            load_tab(2 * i + 1, tq[1]);
+#ifndef C2_NB_ABL
+#define C2_NB_ABL 0
+#endif
+            if (!(C2_NB_ABL & 2)) {
+                load_tab(2 * i + 1, tq[(2 * i + 1) % 3]);
+                if (2 * i + 2 < 2 * NV) load_tab(2 * i + 2, tq[(2 * i + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);  // (keep that order)
+            }
+            if (C2_NB_ABL & 1) {} else
             if (i + 2 < NV) { xq[(i + 2) % 3] = load_x(i + 2, rxc); mq[(i + 2) % 3] = load_m(i + 2, rgc); }
             else { xq[(i + 2) % 3] = load_x(i + 2 - NV, nrx); mq[(i + 2) % 3] = load_m(i + 2 - NV, nrg); }
+            // ... and chunk i of the NEXT row's logits: one chunk per chunk, so that the CUs (which walk their rows in step)
+            // draw on HBM evenly -- requested all at once at the top of the pass, 256 x 76 KB queued up in front of the
+            // table loads of the first chunks
+            nx[i] = load_o(i, nrl);
             if (4 * (tid + NT * i) < Gi) {  // (waves wholly past the last gene skip the chunk)
                 f32x4 dt4, pg4;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) if (4 * (tid + NT * i) + 2 * h < always) {  // (its own basic block, as above)
-                    if (h == 1 && 2 * i + 2 < 2 * NV) load_tab(2 * i + 2, tq[0]);  // first pair of the next chunk
                     // keep-mask of the two genes as 0/1 floats (0 past the last gene: the mask load returned zeros); a
                     // count under a cleared mask may hold anything (the reference zeroes ll there after the fact): it is
                     // replaced by 0 so that everything below is finite
@@ -589,22 +657,15 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                     const f32x2 mf = f32x2{b0 != 0.f ? 1.f : 0.f, b1 != 0.f ? 1.f : 0.f};
                     const f32x2 x = f32x2{b0 != 0.f ? xcur[2 * h] : 0.f, b1 != 0.f ? xcur[2 * h + 1] : 0.f};
                     const f32x2 e = f32x2{ev[i][2 * h], ev[i][2 * h + 1]};
-                    const f32x2 th = tq[h][0], k1 = tq[h][1], k2 = tq[h][2];  // (pair 2i + h: slot h)
-                    const f32x2 mu = e * cmu;
-                    const f32x2 mue = mu + eps2;
-                    const f32x2 tm = th + mue;
-                    const f32x2 rtm = vrcp(tm), ltm = vlog(tm);
-                    const f32x2 rme = vrcp(mue), lme = vlog(mue);
-                    const f32x2 zt = x + th;
-                    f32x2 lg, dg;
-                    lgam_digam2(zt, lg, dg);
-                    // ll = K1 - (theta+x) log(theta+mu+eps) + x log(mu+eps) + lgamma(x+theta) - lgamma(x+1)
-                    f32x2 ll = k1 - zt * ltm + x * lme + lg;
+#if C2_NB_ABL & 4
+                    NbPair g; g.ll = x * e + tq[(2 * i + h) % 3][1]; g.dmu_mu = x + e * tq[(2 * i + h) % 3][0]; g.dth = x - e + tq[(2 * i + h) % 3][2];
+#else
+                    const NbPair g = nb_pair(x, e, tq[(2 * i + h) % 3][0], tq[(2 * i + h) % 3][1], tq[(2 * i + h) % 3][2], cmu);
+#endif
+                    const f32x2 th = tq[(2 * i + h) % 3][0];
+                    f32x2 ll = g.ll;
                     if (!HAS_LGX) ll -= f32x2{lgamma_fast(x[0] + 1.0f), lgamma_fast(x[1] + 1.0f)};
-                    // mu * dll/dmu = x mu/(mu+eps) - (theta+x) mu/(theta+mu+eps)
-                    const f32x2 dmu_mu = x * (mu * rme) - zt * (mu * rtm);
-                    // dll/dtheta = K2 - log(theta+mu+eps) - (theta+x)/(theta+mu+eps) + digamma(x+theta)
-                    const f32x2 dth = k2 - ltm - zt * rtm + dg;
+                    const f32x2 dmu_mu = g.dmu_mu, dth = g.dth;
                     const f32x2 smf = mf * v2(scale);
                     const f32x2 pgh = smf * dmu_mu;  // p * dloss/dp
                     const f32x2 dth2 = smf * (th * dth);
@@ -613,14 +674,20 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                     S2 += pgh;
                     L2 += mf * ll;
                 }
+#if C2_NB_ABL & 8
+                S2 += f32x2{dt4[0] + pg4[1], dt4[2] + pg4[3]} + f32x2{dt4[1] + pg4[0], dt4[3] + pg4[2]};
+#else
                 f32x4 acc = *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i));
                 acc += dt4;
                 *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = acc;
                 *reinterpret_cast<f32x4*>(pgl + 4 * (tid + NT * i)) = pg4;
+#endif
             }
         }
         loss_acc += L2[0] + L2[1];
+        C2_PH(3)
         const float S = block_sum<NT>(S2[0] + S2[1], red);
+        C2_PH(4)
         // ---- pass B
         const float cS = inv_sum * S;
         const auto rd = row_rsrc(reinterpret_cast<TD*>(a.dlogits) + row * a.lddl, Gi * (int)sizeof(TD));
@@ -645,7 +712,14 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             }
         }
         if (HAS_LGX && tid == 0) loss_acc -= lgx_row;
+        C2_PH(5)
     }
+#ifdef C2_NB_DBG
+    if ((tid & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && (tid == 0 || tid == 704))
+        printf("nb phases blk %d wave %d: head+max %lld | max-barrier %lld | exp+sum-barrier %lld | passA %lld | S-barrier %lld | passB %lld\n",
+               (int)blockIdx.x, tid >> 6, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+#endif
+#undef C2_PH
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
     if (tid == 0) {
@@ -912,6 +986,23 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G + B + 64);
 }
 
+// Workgroup size and chunks per thread of the fast kernel for G genes, or {0, 0}: the general kernel runs.
+struct NbFast { int nt, nv; };
+static NbFast nb_fast_shape(int64_t G, bool vec) {
+    const size_t lds = (size_t)((G + 3) & ~int64_t(3)) * sizeof(float);
+    if (!vec || 2 * lds + 256 > 160 * 1024) return {0, 0};  // two LDS rows must fit the CU (G <= 20 448)
+    if (G <= 1024) return {128, 2};  // (the rolling prefetch needs at least two chunks)
+    if (G <= 2048) return {256, 2};
+    if (G <= 4096) return {256, 4};
+    if (G <= 8192) return {1024, 2};
+    if (G <= 12288) return {1024, 3};
+    if (G <= 15360) return {768, 5};
+    if (G <= 18432) return {768, 6};
+    // (measured at 4096 x 19000: 768 x 7 320 us; 1024 x 5, four waves per SIMD but 128 registers and 22 of them spilled,
+    // 411 us)
+    return {768, 7};
+}
+
 template <typename TD>
 static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     const size_t lds = (size_t)((a.G + 3) & ~int64_t(3)) * sizeof(float);
@@ -939,19 +1030,17 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
         else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), l, st, a);                                        \
         return 0;                                                                                             \
     } while (0)
-    if (vec && 2 * lds + 256 <= 160 * 1024) {  // two LDS rows fit the CU (G <= 20 448)
-        const int64_t G = a.G;
-        if (G <= 1024) NB_F(128, 2);  // (the rolling prefetch needs at least two chunks)
-        if (G <= 2048) NB_F(256, 2);
-        if (G <= 4096) NB_F(256, 4);
-        if (G <= 8192) NB_F(1024, 2);
-        if (G <= 12288) NB_F(1024, 3);
-        if (G <= 15360) NB_F(768, 5);
-        if (G <= 18432) NB_F(768, 6);
-        // (measured at 4096 x 19000: 768 x 7 320 us; 1024 x 5, four waves per SIMD but 128 registers and 22 of them spilled,
-        // 411 us)
-        if (G <= 20448) NB_F(768, 7);
-    }
+    const NbFast f = nb_fast_shape(a.G, vec);
+#define NB_FC(NT, NV) if (f.nt == NT && f.nv == NV) NB_F(NT, NV)
+    NB_FC(128, 2);
+    NB_FC(256, 2);
+    NB_FC(256, 4);
+    NB_FC(1024, 2);
+    NB_FC(1024, 3);
+    NB_FC(768, 5);
+    NB_FC(768, 6);
+    NB_FC(768, 7);
+#undef NB_FC
     if (a.G <= 4096) NB_L(256);
     else NB_L(1024);
 #undef NB_L
@@ -980,13 +1069,13 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     float* part2 = part_loss + ngroups + 32;
     int* rowflags = reinterpret_cast<int*>(part2 + (int64_t)kDthSlices * 3 * G) + 16;
-    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
-                       cond, B, rowflags);
-    NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags};
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
+    hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
+                       cond, B, rowflags, status_dev, nb_fast_shape(G, vec).nt);
+    NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
+             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags};
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
@@ -1017,7 +1106,7 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
-                       (const int64_t*)nullptr, (int64_t)0, (int*)nullptr);
+                       (const int64_t*)nullptr, (int64_t)0, (int*)nullptr, (int32_t*)nullptr, 0);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     ZinbExtra z{pi, dpi, ldpi, lddpi};

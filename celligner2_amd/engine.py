@@ -932,6 +932,8 @@ class StepEngine:
         s = st.tolist()
         if s[0] or s[1]:
             st.zero_()
+        if s[0] == 2:
+            raise ValueError("NB dispersion exp(theta) below 1e-17 (or not a number): outside the loss kernel's domain")
         if s[0]:
             raise IndexError("condition values outside {0,1} reached the NB dispersion one-hot "
                              "(the reference's scatter_ raises 'index out of range' here)")
