@@ -68,7 +68,7 @@ __host__ __device__ inline int64_t nb_tab_ld(int64_t G) { return (G + 12287) / 1
 // 2 = it holds a 1, 4 = an entry outside {0,1} or >= C), so that the loss kernel fetches ONE word per row, a row ahead.
 __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab,
                                 const int64_t* __restrict__ cond, int64_t B, int* __restrict__ rowflags,
-                                int32_t* __restrict__ status, int pair_nt) {
+                                int32_t* __restrict__ status) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (rowflags) {
         for (int64_t r = g; r < B; r += (int64_t)gridDim.x * blockDim.x) {
@@ -81,21 +81,12 @@ __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t 
         }
     }
     if (g >= Gp) return;
-    // where gene g sits inside a plane: in gene order, or (pair_nt = the fast loss kernel's workgroup size) in the order
-    // that kernel reads it -- thread t of pair_nt owns genes 4 (t + pair_nt i) .. + 3 of chunk i and takes them as two
-    // pairs; the pairs of one (chunk, half) lie side by side, so that a wave's 8-byte loads cover whole cache lines
-    // (in gene order they took every other 8 bytes, and each line was fetched from L2 twice)
-    int64_t at = g;
-    if (pair_nt) {
-        const int64_t q = g >> 2, i = q / pair_nt, t = q - i * pair_nt;
-        at = ((i * 2 + ((g >> 1) & 1)) * pair_nt + t) * 2 + (g & 1);
-    }
     if (g >= G) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            tab[(p * 3 + 0) * Gp + at] = 1.f;
-            tab[(p * 3 + 1) * Gp + at] = 0.f;
-            tab[(p * 3 + 2) * Gp + at] = 0.f;
+            tab[(p * 3 + 0) * Gp + g] = 1.f;
+            tab[(p * 3 + 1) * Gp + g] = 0.f;
+            tab[(p * 3 + 2) * Gp + g] = 0.f;
         }
         return;
     }
@@ -108,9 +99,9 @@ __global__ void nb_table_kernel(const float* __restrict__ theta, int C, int64_t 
         const float lte = logf(th + 1e-8f);
         // the fast loss kernel's domain (nb_pair): a dispersion below 1e-17 is reported, not silently mis-evaluated
         if (status && !(th >= 1e-17f)) *status = 2;
-        tab[(p * 3 + 0) * Gp + at] = th;
-        tab[(p * 3 + 1) * Gp + at] = th * lte - lgamma_pos(th);
-        tab[(p * 3 + 2) * Gp + at] = lte + th / (th + 1e-8f) - digamma_pos(th);
+        tab[(p * 3 + 0) * Gp + g] = th;
+        tab[(p * 3 + 1) * Gp + g] = th * lte - lgamma_pos(th);
+        tab[(p * 3 + 2) * Gp + g] = lte + th / (th + 1e-8f) - digamma_pos(th);
     }
 }
 
@@ -406,10 +397,13 @@ __device__ __forceinline__ f32x2 vlog2(f32x2 v) {  // base-2 log, arguments norm
 //   C = log mue
 //   Bq = log(zs^5 / P^2)       -> ll = K1 + z A + x C + Bq / 2 - zs + log sqrt(2 pi) + [lgamma series]
 //   (z log tm - (zs - 1/2) log zs + log P  =  -z A - 5/2 log zs + log P, since zs - 1/2 - z = 5/2).
+// K1 and K2 are NOT added here: they enter the row's loss and the dispersion gradient only through sums over the kept
+// genes, sum_g m_g K1_g and theta_g K2_g sum_rows m_g, which the kernel forms from per-gene counts of kept entries when
+// it flushes its accumulator -- so the row loop reads ONE table value per gene (theta), not three.
 // Domain: zs^5 / P^2 and 1 / (zs P) must be normal floats: 1e-18 <= x + theta <= 1e9 (nb_table_kernel raises the
 // status word for a dispersion below that; counts that large are not exact in fp32 anyway).
 struct NbPair { f32x2 ll, dmu_mu, dth; };
-__device__ __forceinline__ NbPair nb_pair(f32x2 x, f32x2 e, f32x2 th, f32x2 k1, f32x2 k2, f32x2 cmu) {
+__device__ __forceinline__ NbPair nb_pair(f32x2 x, f32x2 e, f32x2 th, f32x2 cmu) {
     const f32x2 ln2 = v2(0.6931471805599453f);
     const f32x2 mu = e * cmu;
     const f32x2 mue = mu + v2(1e-8f);
@@ -429,11 +423,48 @@ __device__ __forceinline__ NbPair nb_pair(f32x2 x, f32x2 e, f32x2 th, f32x2 k1, 
     const f32x2 r2 = r * r;
     NbPair o;
     const f32x2 lser = r * (v2(0.083333333333f) + r2 * (v2(-0.002777777778f) + r2 * v2(0.000793650794f)));
-    o.ll = (z * A + x * C + v2(0.5f) * Bq) * ln2 + ((k1 - zs) + v2(0.918938533205f) + lser);
+    o.ll = (z * A + x * C + v2(0.5f) * Bq) * ln2 + ((v2(0.918938533205f) - zs) + lser);
     o.dmu_mu = (mu * R1) * (th * (x - mue));
     const f32x2 dser = r * (v2(0.5f) + r * (v2(0.083333333333f) - r2 * (v2(0.008333333333f) - r2 * v2(0.003968253968f))));
-    o.dth = A * ln2 + (k2 - z * rtm - dser - dP * rP);
+    o.dth = A * ln2 - (z * rtm + dser + dP * rP);
     return o;
+}
+
+#ifndef C2_NB_ABL
+#define C2_NB_ABL 0  // ablation builds only
+#endif
+// Block-wide max / sum for the fast NB kernel, three per row.  The wave step runs on DPP lane moves (a few VALU cycles each;
+// __shfl_xor goes through the LDS crossbar, a ~100-cycle round trip per step and six steps in a chain), and ONE barrier
+// serves a reduction: the waves' partials go to alternating halves of `red`, so the partials of reduction k are
+// overwritten by reduction k + 2, which every wave reaches only through the barrier of k + 1.  EXEC must be all ones.
+template <bool IS_MAX>
+__device__ __forceinline__ float nb_wave_reduce(float v) {
+#define C2_DPP(x, ctrl, rows, oldv)                                                                            \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(oldv)), __builtin_bit_cast(int, x), \
+                                                          ctrl, rows, 0xF, false))
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    v = op(v, C2_DPP(v, 0xB1, 0xF, v));   // quad_perm [1,0,3,2]
+    v = op(v, C2_DPP(v, 0x4E, 0xF, v));   // quad_perm [2,3,0,1]
+    v = op(v, C2_DPP(v, 0x141, 0xF, v));  // row_half_mirror: the other quad of each 8
+    v = op(v, C2_DPP(v, 0x140, 0xF, v));  // row_mirror: the other 8 of each row of 16
+    v = op(v, C2_DPP(v, 0x142, 0xA, IS_MAX ? v : 0.f));  // row_bcast15 into rows 1 and 3
+    v = op(v, C2_DPP(v, 0x143, 0xC, IS_MAX ? v : 0.f));  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's value
+#undef C2_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <bool IS_MAX, int NT>
+__device__ __forceinline__ float nb_block_reduce(float v, float* red, int& half) {
+    constexpr int NW = NT / 64;
+    static_assert(NW <= 16, "two halves of 16 partials");
+    v = nb_wave_reduce<IS_MAX>(v);
+    float* r = red + half;
+    half ^= 16;
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+    if (!(C2_NB_ABL & 32)) __syncthreads();
+    float s = r[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s = IS_MAX ? fmaxf(s, r[i]) : s + r[i];
+    return s;
 }
 
 // Fast path (16-byte aligned rows, G % 4 == 0): one workgroup walks whole rows; thread t owns columns
@@ -462,8 +493,36 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     float* pgl = dacc + G4;  // [G4] floats: p * dloss/dp of the row in flight
     for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
     int cur_pat = -1, flushed = 0;
+    int red_half = 0;  // which half of `red` the next block reduction writes
     float loss_acc = 0.f;
+    // kept[i]: per gene of chunk i (one byte each), the number of rows since the last flush in which the gene was kept by
+    // the mask.  K1 and K2 of the log-likelihood depend on the gene and the row's pattern only, so what they add to the
+    // loss and to the dispersion gradient over those rows is K1_g * kept_g and scale * theta_g * K2_g * kept_g: added
+    // when the accumulator is flushed (the pattern changes, 255 rows have gone by, the walk ends), not per row.
+    unsigned kept[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) kept[i] = 0u;
+    int rows_kept = 0;
     auto flush = [&](int pat) {
+        const int64_t Gp = nb_tab_ld(G);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * (tid + NT * i);
+            if (c < Gi) {
+                const f32x4 th4 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 0) * Gp + c);
+                const f32x4 k14 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 1) * Gp + c);
+                const f32x4 k24 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 2) * Gp + c);
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n4[e] = (float)((kept[i] >> (8 * e)) & 0xffu);
+                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c);
+                acc += (-a.inv_B) * (th4 * k24 * n4);
+                *reinterpret_cast<f32x4*>(dacc + c) = acc;
+                loss_acc += (k14[0] * n4[0] + k14[1] * n4[1]) + (k14[2] * n4[2] + k14[3] * n4[3]);
+            }
+            kept[i] = 0u;
+        }
+        rows_kept = 0;
         __syncthreads();
         float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
         const bool first = !((flushed >> pat) & 1);
@@ -477,7 +536,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     f32x4 ev[NV], nx[NV];
     f32x4 xq[3];       // counts of chunks i, i+1, i+2 (slot = chunk % 3)
     unsigned mq[3];    // their masks
-    f32x2 tq[3][3];    // theta, K1, K2 of this gene pair and of the next two (slot = pair % 3)
+    f32x4 tq[2];       // theta of this chunk's four genes and of the next chunk's (slot = chunk % 2)
     const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     // Rows are addressed through buffer resources (base = the row, extent = its G elements): every lane of every wave
     // issues every memory operation of every chunk -- a lane past the last gene loads zeros and its store is dropped
@@ -538,6 +597,10 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         return m;
     };
     RowMeta nmeta = load_meta(blockIdx.x);
+    {
+        const int pat0 = ((nmeta.flags & 1) && (nmeta.flags & 2)) ? 2 : ((nmeta.flags & 2) ? 1 : 0);
+        tq[NV % 2] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat0 * 3) * nb_tab_ld(G) + 4 * tid);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // The workgroups walk rows of equal cost and would stay in step, every CU of an XCD asking for its logits, counts and
     // stores in the same microsecond: every second one starts 2, 4 or 6 us late (same-box A/B: 277 -> 272 us).
@@ -559,10 +622,11 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         // host raises when it reads the status word) so that the prefetch chain is not broken
         if ((bad || (!has0 && !has1)) && tid == 0) *a.status = 1;
         const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
-        if (pat != cur_pat) {
+        if (pat != cur_pat || rows_kept == 255) {
             if (cur_pat >= 0) flush(cur_pat);
             cur_pat = pat;
         }
+        ++rows_kept;
 #pragma unroll
         for (int i = 0; i < NV; ++i) ev[i] = nx[i];
         const bool rotate = true;
@@ -581,9 +645,12 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         const float sf = meta.sf;
         const float lgx_row = meta.lgx;
         const int64_t Gp = nb_tab_ld(G);
-        const float* tth = a.tab + (int64_t)(pat * 3 + 0) * Gp + 2 * tid;  // (pair order: nb_table_kernel, pair_nt = NT)
-        const float* tk1 = a.tab + (int64_t)(pat * 3 + 1) * Gp + 2 * tid;
-        const float* tk2 = a.tab + (int64_t)(pat * 3 + 2) * Gp + 2 * tid;
+        // theta of the row's pattern, four genes per lane and chunk (K1 and K2 are read when the accumulator is flushed);
+        // the last chunk requests the first chunk's theta of the NEXT row's pattern
+        const float* tth = a.tab + (int64_t)(pat * 3) * Gp + 4 * tid;
+        const int nfl = has_next ? nmeta.flags : meta.flags;
+        const int npat = ((nfl & 1) && (nfl & 2)) ? 2 : ((nfl & 2) ? 1 : 0);
+        const float* tth_n = a.tab + (int64_t)(npat * 3) * Gp + 4 * tid;
         const float scale = -a.inv_B;
         float mx = -INFINITY;
 #pragma unroll
@@ -592,7 +659,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
         }
         C2_PH(0)
-        mx = block_max<NT>(mx, red);
+        mx = nb_block_reduce<true, NT>(mx, red, red_half);
         C2_PH(1)
         float sm = 0.f;
 #pragma unroll
@@ -602,19 +669,15 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                 ev[i][k] = fexp(ev[i][k] - mx);
                 sm += ev[i][k];
             }
-        sm = block_sum<NT>(sm, red);
+        sm = nb_block_reduce<false, NT>(sm, red, red_half);
         C2_PH(2)
         const float inv_sum = 1.0f / sm;
         const f32x2 cmu = v2(sf * inv_sum);
         // ---- pass A
         f32x2 S2 = v2(0.f), L2 = v2(0.f);
-        // (padded table: always in bounds; 8 bytes per lane and load, L2-resident, requested one gene pair ahead)
-        auto load_tab = [&](int pair, f32x2 (&t)[3]) {
-            t[0] = *reinterpret_cast<const f32x2*>(tth + 2 * NT * pair);
-            t[1] = *reinterpret_cast<const f32x2*>(tk1 + 2 * NT * pair);
-            t[2] = *reinterpret_cast<const f32x2*>(tk2 + 2 * NT * pair);
-        };
-        load_tab(0, tq[0]);
+        // (padded table: always in bounds; 16 bytes per lane and chunk, L2-resident, requested one chunk ahead)
+        auto load_th = [&](int i, const float* t) { return *reinterpret_cast<const f32x4*>(t + 4 * NT * i); };
+        if (NV % 2 == 1) tq[0] = tq[1];  // (chunk NV of the previous row = chunk 0 of this one landed in slot NV % 2)
         if (rotate) {
             // The previous row's last two chunks requested this row's chunks 0 and 1 into the slots they had free (chunk
             // NV + k lands in slot (NV + k) % 3): rotate them to slots 0 and 1.  Done HERE and not at the head of the row:
@@ -629,14 +692,10 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             // when this row ends) into the slot chunk i - 1 has released
             const f32x4 xcur = xq[i % 3];
             const unsigned mcur = mq[i % 3];
-            // table values of the chunk's SECOND gene pair first, the counts of chunk i + 2 after them: vmcnt counts in
-            // issue order, so a table load issued after the (HBM) count loads could only be waited for together with them
-#ifndef C2_NB_ABL
-#define C2_NB_ABL 0
-#endif
+            // the next chunk's theta first, the counts of chunk i + 2 after it: vmcnt counts in issue order, so a table
+            // load issued after the (HBM) count loads could only be waited for together with them
             if (!(C2_NB_ABL & 2)) {
-                load_tab(2 * i + 1, tq[(2 * i + 1) % 3]);
-                if (2 * i + 2 < 2 * NV) load_tab(2 * i + 2, tq[(2 * i + 2) % 3]);
+                tq[(i + 1) % 2] = (i + 1 < NV) ? load_th(i + 1, tth) : load_th(0, tth_n);
                 __builtin_amdgcn_sched_barrier(0);  // (keep that order)
             }
             if (C2_NB_ABL & 1) {} else
@@ -645,7 +704,13 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             // ... and chunk i of the NEXT row's logits: one chunk per chunk, so that the CUs (which walk their rows in step)
             // draw on HBM evenly -- requested all at once at the top of the pass, 256 x 76 KB queued up in front of the
             // table loads of the first chunks
-            nx[i] = load_o(i, nrl);
+            if (!(C2_NB_ABL & 64)) nx[i] = load_o(i, nrl);
+            {  // one more row for the genes the mask keeps (bytes of any non-zero value count as 1)
+                unsigned t = mcur | (mcur >> 4);
+                t |= t >> 2;
+                t |= t >> 1;
+                kept[i] += t & 0x01010101u;
+            }
             if (4 * (tid + NT * i) < Gi) {  // (waves wholly past the last gene skip the chunk)
                 f32x4 dt4, pg4;
 #pragma unroll
@@ -657,12 +722,12 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                     const f32x2 mf = f32x2{b0 != 0.f ? 1.f : 0.f, b1 != 0.f ? 1.f : 0.f};
                     const f32x2 x = f32x2{b0 != 0.f ? xcur[2 * h] : 0.f, b1 != 0.f ? xcur[2 * h + 1] : 0.f};
                     const f32x2 e = f32x2{ev[i][2 * h], ev[i][2 * h + 1]};
+                    const f32x2 th = f32x2{tq[i % 2][2 * h], tq[i % 2][2 * h + 1]};
 #if C2_NB_ABL & 4
-                    NbPair g; g.ll = x * e + tq[(2 * i + h) % 3][1]; g.dmu_mu = x + e * tq[(2 * i + h) % 3][0]; g.dth = x - e + tq[(2 * i + h) % 3][2];
+                    NbPair g; g.ll = x * e + th; g.dmu_mu = x + e * th; g.dth = x - e + th;
 #else
-                    const NbPair g = nb_pair(x, e, tq[(2 * i + h) % 3][0], tq[(2 * i + h) % 3][1], tq[(2 * i + h) % 3][2], cmu);
+                    const NbPair g = nb_pair(x, e, th, cmu);
 #endif
-                    const f32x2 th = tq[(2 * i + h) % 3][0];
                     f32x2 ll = g.ll;
                     if (!HAS_LGX) ll -= f32x2{lgamma_fast(x[0] + 1.0f), lgamma_fast(x[1] + 1.0f)};
                     const f32x2 dmu_mu = g.dmu_mu, dth = g.dth;
@@ -686,7 +751,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         }
         loss_acc += L2[0] + L2[1];
         C2_PH(3)
-        const float S = block_sum<NT>(S2[0] + S2[1], red);
+        const float S = nb_block_reduce<false, NT>(S2[0] + S2[1], red, red_half);
         C2_PH(4)
         // ---- pass B
         const float cS = inv_sum * S;
@@ -708,7 +773,8 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                 u32x2 pk;
                 pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
                 pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rd, tid * 8, i * NT * 8, 0);
+                if (!(C2_NB_ABL & 128)) __builtin_amdgcn_raw_buffer_store_b64(pk, rd, tid * 8, i * NT * 8, 0);
+                else asm volatile("" :: "v"(pk));
             }
         }
         if (HAS_LGX && tid == 0) loss_acc -= lgx_row;
@@ -1073,7 +1139,7 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
-                       cond, B, rowflags, status_dev, nb_fast_shape(G, vec).nt);
+                       cond, B, rowflags, status_dev);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags};
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
@@ -1106,7 +1172,7 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
-                       (const int64_t*)nullptr, (int64_t)0, (int*)nullptr, (int32_t*)nullptr, 0);
+                       (const int64_t*)nullptr, (int64_t)0, (int*)nullptr, (int32_t*)nullptr);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     ZinbExtra z{pi, dpi, ldpi, lddpi};
