@@ -481,7 +481,10 @@ __device__ __forceinline__ float nb_block_reduce(float v, float* red, int& half)
 //   pass A: everything per gene -- log-likelihood, d(theta) into the LDS accumulator, p * dloss/dp and its row sum S;
 //   pass B: dlogits = p * dloss/dp - p * S, stored once.
 // Nothing is recomputed between the passes.  Needs accumulator + the second row in the CU's 160 KB (G <= 20 448).
-template <typename TD, int NT, int NV, bool HAS_LGX>
+// REGT (512 threads x 10 chunks at 19k genes: two waves per SIMD, 256 registers each): theta of the thread's genes and
+// the dispersion-gradient accumulator live in REGISTERS as well -- the row loop then reads no table at all and the only
+// LDS traffic left is p * dloss/dp between the passes (one LDS row: G <= 40 000 fits, NV caps it at 20 480 here).
+template <typename TD, int NT, int NV, bool HAS_LGX, bool REGT = false>
 __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     static_assert(NV >= 2, "the rolling prefetch of counts reaches two chunks ahead");
     extern __shared__ __attribute__((aligned(16))) float dacc[];
@@ -490,8 +493,12 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     const int64_t G = a.G;
     const int Gi = (int)G;
     const int G4 = (Gi + 3) & ~3;
-    float* pgl = dacc + G4;  // [G4] floats: p * dloss/dp of the row in flight
-    for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
+    float* pgl = dacc + (REGT ? 0 : G4);  // [G4] floats: p * dloss/dp of the row in flight
+    if (!REGT)
+        for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
+    f32x4 thr[REGT ? NV : 1], dreg[REGT ? NV : 1];  // REGT: theta of the current pattern, d(theta) accumulator
+#pragma unroll
+    for (int i = 0; i < (REGT ? NV : 1); ++i) dreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int cur_pat = -1, flushed = 0;
     int red_half = 0;  // which half of `red` the next block reduction writes
     float loss_acc = 0.f;
@@ -505,6 +512,8 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     int rows_kept = 0;
     auto flush = [&](int pat) {
         const int64_t Gp = nb_tab_ld(G);
+        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
+        const bool first = !((flushed >> pat) & 1);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * (tid + NT * i);
@@ -515,23 +524,41 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                 f32x4 n4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) n4[e] = (float)((kept[i] >> (8 * e)) & 0xffu);
-                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c);
-                acc += (-a.inv_B) * (th4 * k24 * n4);
-                *reinterpret_cast<f32x4*>(dacc + c) = acc;
+                const f32x4 add = (-a.inv_B) * (th4 * k24 * n4);
+                if (REGT) {  // every thread owns its genes: no LDS, no barrier
+                    f32x4 acc = dreg[i] + add;
+                    if (!first) acc += *reinterpret_cast<const f32x4*>(dst + c);
+                    *reinterpret_cast<f32x4*>(dst + c) = acc;
+                    dreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c);
+                    acc += add;
+                    *reinterpret_cast<f32x4*>(dacc + c) = acc;
+                }
                 loss_acc += (k14[0] * n4[0] + k14[1] * n4[1]) + (k14[2] * n4[2] + k14[3] * n4[3]);
             }
             kept[i] = 0u;
         }
         rows_kept = 0;
+        flushed |= 1 << pat;
+        if (REGT) return;
         __syncthreads();
-        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
-        const bool first = !((flushed >> pat) & 1);
         for (int64_t c = tid; c < G; c += NT) {
             dst[c] = first ? dacc[c] : dst[c] + dacc[c];
             dacc[c] = 0.f;
         }
-        flushed |= 1 << pat;
         __syncthreads();
+    };
+    // REGT: theta of pattern `pat` into the registers, waited for here (a pattern change is rare), and handed through empty
+    // statements so that the row loop's counted vmcnt waits are not sized for this path
+    auto load_thr = [&](int pat) {
+        if (!REGT) return;
+        const float* t = a.tab + (int64_t)(pat * 3) * nb_tab_ld(G) + 4 * tid;
+#pragma unroll
+        for (int i = 0; i < (REGT ? NV : 1); ++i) thr[i] = *reinterpret_cast<const f32x4*>(t + 4 * NT * i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < (REGT ? NV : 1); ++i) asm volatile("" : "+v"(thr[i]));
     };
     f32x4 ev[NV], nx[NV];
     f32x4 xq[3];       // counts of chunks i, i+1, i+2 (slot = chunk % 3)
@@ -599,9 +626,19 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     RowMeta nmeta = load_meta(blockIdx.x);
     {
         const int pat0 = ((nmeta.flags & 1) && (nmeta.flags & 2)) ? 2 : ((nmeta.flags & 2) ? 1 : 0);
-        tq[NV % 2] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat0 * 3) * nb_tab_ld(G) + 4 * tid);
+        if (!REGT) tq[NV % 2] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat0 * 3) * nb_tab_ld(G) + 4 * tid);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (REGT) {
+        // (the compiler does not see that wait: hand the loaded registers through empty statements, so that on this way
+        // into the loop they are plain values and the row-head waits are counted on the loop's own order of requests --
+        // sized for this path they were full drains that waited out the stores of pass B; at 768 x 7 the same change
+        // measured 2 % slower and is not applied there)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(nx[i]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(xq[k]), "+v"(mq[k]));
+    }
     // The workgroups walk rows of equal cost and would stay in step, every CU of an XCD asking for its logits, counts and
     // stores in the same microsecond: every second one starts 2, 4 or 6 us late (same-box A/B: 277 -> 272 us).
 #ifndef C2_NB_STAGGER
@@ -624,6 +661,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         const int pat = (has0 && has1) ? 2 : (has1 ? 1 : 0);
         if (pat != cur_pat || rows_kept == 255) {
             if (cur_pat >= 0) flush(cur_pat);
+            if (pat != cur_pat) load_thr(pat);
             cur_pat = pat;
         }
         ++rows_kept;
@@ -677,7 +715,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         f32x2 S2 = v2(0.f), L2 = v2(0.f);
         // (padded table: always in bounds; 16 bytes per lane and chunk, L2-resident, requested one chunk ahead)
         auto load_th = [&](int i, const float* t) { return *reinterpret_cast<const f32x4*>(t + 4 * NT * i); };
-        if (NV % 2 == 1) tq[0] = tq[1];  // (chunk NV of the previous row = chunk 0 of this one landed in slot NV % 2)
+        if (!REGT && NV % 2 == 1) tq[0] = tq[1];  // (chunk NV of the previous row = chunk 0 of this one landed in slot NV % 2)
         if (rotate) {
             // The previous row's last two chunks requested this row's chunks 0 and 1 into the slots they had free (chunk
             // NV + k lands in slot (NV + k) % 3): rotate them to slots 0 and 1.  Done HERE and not at the head of the row:
@@ -694,7 +732,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             const unsigned mcur = mq[i % 3];
             // the next chunk's theta first, the counts of chunk i + 2 after it: vmcnt counts in issue order, so a table
             // load issued after the (HBM) count loads could only be waited for together with them
-            if (!(C2_NB_ABL & 2)) {
+            if (!REGT && !(C2_NB_ABL & 2)) {
                 tq[(i + 1) % 2] = (i + 1 < NV) ? load_th(i + 1, tth) : load_th(0, tth_n);
                 __builtin_amdgcn_sched_barrier(0);  // (keep that order)
             }
@@ -722,7 +760,8 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                     const f32x2 mf = f32x2{b0 != 0.f ? 1.f : 0.f, b1 != 0.f ? 1.f : 0.f};
                     const f32x2 x = f32x2{b0 != 0.f ? xcur[2 * h] : 0.f, b1 != 0.f ? xcur[2 * h + 1] : 0.f};
                     const f32x2 e = f32x2{ev[i][2 * h], ev[i][2 * h + 1]};
-                    const f32x2 th = f32x2{tq[i % 2][2 * h], tq[i % 2][2 * h + 1]};
+                    const f32x2 th = REGT ? f32x2{thr[REGT ? i : 0][2 * h], thr[REGT ? i : 0][2 * h + 1]}
+                                          : f32x2{tq[i % 2][2 * h], tq[i % 2][2 * h + 1]};
 #if C2_NB_ABL & 4
                     NbPair g; g.ll = x * e + th; g.dmu_mu = x + e * th; g.dth = x - e + th;
 #else
@@ -742,9 +781,13 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
 #if C2_NB_ABL & 8
                 S2 += f32x2{dt4[0] + pg4[1], dt4[2] + pg4[3]} + f32x2{dt4[1] + pg4[0], dt4[3] + pg4[2]};
 #else
-                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i));
-                acc += dt4;
-                *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = acc;
+                if (REGT) {
+                    dreg[REGT ? i : 0] += dt4;
+                } else {
+                    f32x4 acc = *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i));
+                    acc += dt4;
+                    *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = acc;
+                }
                 *reinterpret_cast<f32x4*>(pgl + 4 * (tid + NT * i)) = pg4;
 #endif
             }
@@ -1066,6 +1109,10 @@ static NbFast nb_fast_shape(int64_t G, bool vec) {
     if (G <= 18432) return {768, 6};
     // (measured at 4096 x 19000: 768 x 7 320 us; 1024 x 5, four waves per SIMD but 128 registers and 22 of them spilled,
     // 411 us)
+    // (same box, 4096 x 19000: 768 x 7 with theta re-read per row 238 us, 512 x 10 with theta and the accumulator in
+    // registers 232 us; C2_NB_REGT=0 selects the former: A/B and tests)
+    const char* e = getenv("C2_NB_REGT");
+    if (e == nullptr || atoi(e) != 0) return {512, 10};
     return {768, 7};
 }
 
@@ -1085,9 +1132,10 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     } while (0)
 #define NB_F(NT, NV)                                                                                          \
     do {                                                                                                      \
-        auto kf = nb_rowreg_kernel<TD, NT, NV, false>;                                                         \
-        auto kl = nb_rowreg_kernel<TD, NT, NV, true>;                                                          \
-        const size_t l = 2 * lds; /* the accumulator and the row of p * dloss/dp */                            \
+        constexpr bool regt = (NT) == 512;                                                                     \
+        auto kf = nb_rowreg_kernel<TD, NT, NV, false, regt>;                                                   \
+        auto kl = nb_rowreg_kernel<TD, NT, NV, true, regt>;                                                    \
+        const size_t l = (regt ? 1 : 2) * lds; /* (the accumulator and) the row of p * dloss/dp */               \
         if (l > 48 * 1024) {                                                                                  \
             (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
             (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
@@ -1106,6 +1154,7 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     NB_FC(768, 5);
     NB_FC(768, 6);
     NB_FC(768, 7);
+    NB_FC(512, 10);
 #undef NB_FC
     if (a.G <= 4096) NB_L(256);
     else NB_L(1024);

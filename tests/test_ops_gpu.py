@@ -386,6 +386,66 @@ def test_recon_nb(B, G, C, multi, dl_dtype):
     assert torch.equal(dl3, dl2) and torch.equal(dth3, dth2)
 
 
+@pytest.mark.parametrize("regt", ["0", "1"])
+def test_recon_nb_row_walks_at_19k_genes(regt, monkeypatch):
+    """Both forms of the fast kernel at the benchmark width (C2_NB_REGT: theta and the accumulator in registers, or theta
+    re-read per row), several rows per workgroup, the row pattern changing inside a workgroup's walk (the accumulator
+    and the kept-entry counts are flushed per pattern) and a tenth of the entries masked."""
+    monkeypatch.setenv("C2_NB_REGT", regt)
+    ops = _ops()
+    rng = np.random.default_rng(19)
+    B, G, C = 600, 19000, 2
+    o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C, multi=True)
+    good &= rng.uniform(size=(B, G)) > 0.1
+    cond[rng.integers(0, B, 40), :] = 1   # pattern "only ones" here and there: blocks see 2 -> 1 -> 2
+    cond[rng.integers(0, B, 40), :] = 0   # and "only zeros"
+    recon64, do64, dth64 = orc.nb_loss(o.astype(np.float64), x.astype(np.float64), good, sf.astype(np.float64),
+                                       theta.astype(np.float64), cond)
+    for dl_dtype in (torch.float32, torch.bfloat16):
+        loss = torch.zeros(1, device=DEV)
+        dl = torch.empty(B, G, device=DEV, dtype=dl_dtype)
+        dth = torch.empty(G, C, device=DEV)
+        status = torch.zeros(1, device=DEV, dtype=torch.int32)
+        ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dth,
+                     torch.empty(ops.recon_nb_ws(B, G, C), device=DEV), status)
+        assert status.item() == 0
+        assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
+        assert rel(dl, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
+        assert rel(dth, dth64) < 1e-4
+
+
+def test_recon_nb_more_than_255_rows_per_workgroup():
+    """The kept-entry counts are bytes: a workgroup that walks more than 255 rows of one pattern flushes in between."""
+    ops = _ops()
+    rng = np.random.default_rng(7)
+    B, G, C = 256 * 300, 96, 3
+    o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C)
+    recon64, do64, dth64 = orc.nb_loss(o.astype(np.float64), x.astype(np.float64), good, sf.astype(np.float64),
+                                       theta.astype(np.float64), cond)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, G, device=DEV)
+    dth = torch.empty(G, C, device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dth,
+                 torch.empty(ops.recon_nb_ws(B, G, C), device=DEV), status)
+    assert status.item() == 0
+    assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
+    assert rel(dl, do64) < 1e-4 and rel(dth, dth64) < 1e-4
+
+
+def test_recon_nb_flags_a_dispersion_below_its_domain():
+    """exp(theta) < 1e-17 is outside the fast kernel's arithmetic (nb_pair): reported through the status word (2)."""
+    ops = _ops()
+    rng = np.random.default_rng(1)
+    o, x, good, sf, theta, cond = _nb_inputs(rng, 4, 64, 2)
+    theta[5, 1] = -45.0
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 0.25, torch.zeros(1, device=DEV),
+                 torch.empty(4, 64, device=DEV), torch.empty(64, 2, device=DEV),
+                 torch.empty(ops.recon_nb_ws(4, 64, 2), device=DEV), status)
+    assert status.item() == 2
+
+
 def test_recon_nb_golden_wide_row():
     """The [4,19000] NB vector produced by the reference itself."""
     ops = _ops()
