@@ -123,6 +123,7 @@ struct NbArgs {
     int C;
     float inv_B;
     const int* rowflags;  // [B] classification of the condition rows (nb_table_kernel); the fast NB kernel only
+    float* part_db;       // NULL, or [ngroups][G]: per-workgroup column sums of dlogits (REGT form of the fast kernel only)
 };
 
 // fast transcendental forms: every argument here is a normal positive float (>= 1e-8)
@@ -493,9 +494,17 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     const int64_t G = a.G;
     const int Gi = (int)G;
     const int G4 = (Gi + 3) & ~3;
-    float* pgl = dacc + (REGT ? 0 : G4);  // [G4] floats: p * dloss/dp of the row in flight
+    float* pgl = dacc + G4;  // [G4] floats: p * dloss/dp of the row in flight
     if (!REGT)
         for (int64_t c = tid; c < G; c += NT) dacc[c] = 0.f;
+    // REGT: the first LDS row is free; when the caller wants the column sums of dlogits (the bias gradient of the layer
+    // that made the logits) they are accumulated there, every thread on the genes it owns (no barrier)
+    const bool want_db = REGT && a.part_db != nullptr;
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (4 * (tid + NT * i) < G4) *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4 thr[REGT ? NV : 1], dreg[REGT ? NV : 1];  // REGT: theta of the current pattern, d(theta) accumulator
 #pragma unroll
     for (int i = 0; i < (REGT ? NV : 1); ++i) dreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -804,6 +813,11 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
             f32x4 pg4 = {0.f, 0.f, 0.f, 0.f};
             if (4 * (tid + NT * i) < Gi) pg4 = *reinterpret_cast<const f32x4*>(pgl + 4 * (tid + NT * i));
             const f32x4 d = pg4 - ev[i] * cS;
+            if (want_db && 4 * (tid + NT * i) < Gi) {
+                f32x4 acc = *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i));
+                acc += d;
+                *reinterpret_cast<f32x4*>(dacc + 4 * (tid + NT * i)) = acc;
+            }
             if (sizeof(TD) == 4) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rd, v16, i * NT * 16, 0);
                 // Observed on gfx950 (ROCm 7.2): a VALU write of this store's first data register in the very next issue
@@ -829,6 +843,13 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
                (int)blockIdx.x, tid >> 6, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
 #endif
 #undef C2_PH
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * (tid + NT * i);
+            if (c < Gi) *reinterpret_cast<f32x4*>(a.part_db + (int64_t)blockIdx.x * G + c) = *reinterpret_cast<const f32x4*>(dacc + c);
+        }
+    }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
     if (tid == 0) {
@@ -841,7 +862,8 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
 // dtheta reduction, stage 1: partial sums over slices of the workgroup partials
 constexpr int kDthSlices = 32;
 __global__ __launch_bounds__(256) void nb_dtheta_stage1(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
-                                                        int ngroups, int64_t G, float* __restrict__ part2 /*[S][3][G]*/) {
+                                                        int ngroups, int64_t G, float* __restrict__ part2 /*[S][4][G]*/,
+                                                        const float* __restrict__ part_db /*NULL or [ngroups][G]*/) {
     const int64_t g = blockIdx.x * 256ll + threadIdx.x;
     const int sl = blockIdx.y;
     const int per = (ngroups + kDthSlices - 1) / kDthSlices;
@@ -852,24 +874,45 @@ __global__ __launch_bounds__(256) void nb_dtheta_stage1(const float* __restrict_
         float s = 0.f;
         for (int grp = g0; grp < g1; ++grp)
             if (part_flag[grp * 3 + p]) s += part_dt[((int64_t)grp * 3 + p) * G + g];
-        part2[((int64_t)sl * 3 + p) * G + g] = s;
+        part2[((int64_t)sl * 4 + p) * G + g] = s;
+    }
+    if (part_db) {  // fourth plane: the workgroups' column sums of dlogits
+        float s = 0.f;
+        for (int grp = g0; grp < g1; ++grp) s += part_db[(int64_t)grp * G + g];
+        part2[((int64_t)sl * 4 + 3) * G + g] = s;
     }
 }
+// column sums of dlogits where the loss kernel did not form them: slice sl of the rows into the fourth plane of part2
+template <typename TD>
+__global__ __launch_bounds__(256) void nb_colsum_kernel(const TD* __restrict__ d, int64_t ld, int64_t B, int64_t G,
+                                                        float* __restrict__ part2) {
+    const int64_t g = blockIdx.x * 256ll + threadIdx.x;
+    const int sl = blockIdx.y;
+    const int64_t per = (B + kDthSlices - 1) / kDthSlices;
+    const int64_t b0 = sl * per, b1 = min(B, b0 + per);
+    if (g >= G) return;
+    float s = 0.f;
+    for (int64_t b = b0; b < b1; ++b) s += ld_as_f32(d + b * ld + g);
+    part2[((int64_t)sl * 4 + 3) * G + g] = s;
+}
 __global__ __launch_bounds__(256) void nb_dtheta_stage2(const float* __restrict__ part2, int64_t G, int C,
-                                                        float* __restrict__ dtheta) {
+                                                        float* __restrict__ dtheta, float* __restrict__ db /*or NULL*/) {
     const int64_t g = blockIdx.x * 256ll + threadIdx.x;
     if (g >= G) return;
-    float s[3] = {0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < 4; ++p) {
+        if (p == 3 && !db) break;
 #pragma unroll 8
-        for (int sl = 0; sl < kDthSlices; ++sl) s[p] += part2[((int64_t)sl * 3 + p) * G + g];
+        for (int sl = 0; sl < kDthSlices; ++sl) s[p] += part2[((int64_t)sl * 4 + p) * G + g];
+    }
     for (int j = 0; j < C; ++j) {
         float v = 0.f;
         if (j == 0) v = s[0] + s[2];
         if (j == 1) v = s[1] + s[2];
         dtheta[g * C + j] = v;
     }
+    if (db) db[g] = s[3];
 }
 
 // Row constant of the NB log-likelihood: out[b] = sum_g goodloc * lgamma(x + 1) -- a function of the data only.
@@ -1092,7 +1135,8 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
     // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
     // ... + dtheta slices + the row classification (B ints)
-    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 3 * G + B + 64);
+    // ... + the workgroups' column sums of dlogits (c2_recon_nb_fwd_bwd_dbias)
+    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 4 * G + B + 64 + ng * G + 64);
 }
 
 // Workgroup size and chunks per thread of the fast kernel for G genes, or {0, 0}: the general kernel runs.
@@ -1135,7 +1179,7 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
         constexpr bool regt = (NT) == 512;                                                                     \
         auto kf = nb_rowreg_kernel<TD, NT, NV, false, regt>;                                                   \
         auto kl = nb_rowreg_kernel<TD, NT, NV, true, regt>;                                                    \
-        const size_t l = (regt ? 1 : 2) * lds; /* (the accumulator and) the row of p * dloss/dp */               \
+        const size_t l = 2 * lds; /* accumulator (or, regt, the column sums of dlogits) + the row of p * dloss/dp */\
         if (l > 48 * 1024) {                                                                                  \
             (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
             (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);          \
@@ -1163,12 +1207,12 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     return 0;
 }
 
-extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+static int recon_nb_run(const float* logits, int64_t ldl, const float* x, int64_t ldx,
                                    const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
                                    const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
                                    void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
                                    int32_t* status_dev, const float* lgx1_rowsum, const int64_t* row_index,
-                                   void* stream) {
+                                   float* dbias, void* stream) {
     C2_CHECK(logits && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dtheta && ws && status_dev,
              "null pointer");
     C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
@@ -1183,22 +1227,55 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
     float* part2 = part_loss + ngroups + 32;
-    int* rowflags = reinterpret_cast<int*>(part2 + (int64_t)kDthSlices * 3 * G) + 16;
+    int* rowflags = reinterpret_cast<int*>(part2 + (int64_t)kDthSlices * 4 * G) + 16;
+    float* part_db = reinterpret_cast<float*>(rowflags + B + 16);
+    part_db += (4 - ((uintptr_t)part_db >> 2 & 3)) & 3;  // 16-byte aligned when ws is
     const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
                      (lddl % 4 == 0) && aligned16(logits) && aligned16(x) && aligned16(dlogits) &&
                      (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
                        cond, B, rowflags, status_dev);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags};
+             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags, nullptr};
+    // the loss kernel forms the column sums itself in its register-resident form; otherwise a column-sum pass follows
+    const bool db_in_kernel = dbias && nb_fast_shape(G, vec).nt == 512;
+    if (db_in_kernel) a.part_db = part_db;
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
-                       ngroups, G, part2);
-    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
+                       ngroups, G, part2, db_in_kernel ? part_db : (const float*)nullptr);
+    if (dbias && !db_in_kernel) {
+        const dim3 grid((unsigned)((G + 255) / 256), kDthSlices);
+        if (dl_dtype == C2_BF16)
+            hipLaunchKernelGGL(nb_colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dlogits, lddl, B, G, part2);
+        else
+            hipLaunchKernelGGL(nb_colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)dlogits, lddl, B, G, part2);
+    }
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta, dbias);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+                                   const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
+                                   const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
+                                   void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
+                                   int32_t* status_dev, const float* lgx1_rowsum, const int64_t* row_index,
+                                   void* stream) {
+    return recon_nb_run(logits, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
+                        dl_dtype, lddl, dtheta, ws, status_dev, lgx1_rowsum, row_index, nullptr, stream);
+}
+
+extern "C" int c2_recon_nb_fwd_bwd_dbias(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+                                         const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                                         const float* theta, const int64_t* cond, int C, int64_t B, int64_t G,
+                                         float inv_B, float* loss_out, void* dlogits, int dl_dtype, int64_t lddl,
+                                         float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
+                                         const int64_t* row_index, float* dbias, void* stream) {
+    C2_CHECK(dbias, "null pointer");
+    return recon_nb_run(logits, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
+                        dl_dtype, lddl, dtheta, ws, status_dev, lgx1_rowsum, row_index, dbias, stream);
 }
 
 extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
@@ -1238,8 +1315,9 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     }
     float* part2 = part_loss + ngroups + 32;
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
-                       ngroups, G, part2);
-    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta);
+                       ngroups, G, part2, (const float*)nullptr);
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta,
+                       (float*)nullptr);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;

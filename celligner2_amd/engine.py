@@ -685,9 +685,14 @@ class StepEngine:
                 xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
             else:
                 xs, gl, ridx = x, batch["goodloc"], None
+            # the loss kernel also sums dlogits over the batch (the output layer's bias gradient) while it has them
+            dbu = None
+            if save and self.p[self.head + ".bias"].requires_grad:
+                dbu = self.buf("dbias.unit", (G,))
+            self._ws["dbias.unit"] = dbu
             ops.recon_nb(logits, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
                          losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
-                         lgx1=batch.get("lgx1"), row_index=ridx)
+                         lgx1=batch.get("lgx1"), row_index=ridx, dbias=dbu)
         elif cfg["recon_loss"] == "mse":
             if x is None:
                 raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")
@@ -767,8 +772,11 @@ class StepEngine:
         if rq(hw):
             self._wgrad(dlogits, self._dlast, hw, alpha=gr)
         if rq(hb):
-            ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
-            ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
+            if self._ws.get("dbias.unit") is not None:  # (NB: formed by the loss kernel)
+                ops.scale(self._ws["dbias.unit"], gr, self.gbuf(hb))
+            else:
+                ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+                ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
         H1 = self.p[hw].shape[1]
         ns1 = self._dgrad_nslab(dlogits, hw)
         ns2 = self._dgrad_nslab(dlogits, self.head2 + ".weight") if self.head2 else 0

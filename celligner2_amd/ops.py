@@ -389,8 +389,9 @@ def nb_row_const(x, goodloc, out=None):
 
 
 def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dtheta, ws, status, lgx1=None,
-             row_index=None):
-    """row_index: x / goodloc are the resident [N,G] matrices, batch row b = their row row_index[b]."""
+             row_index=None, dbias=None):
+    """row_index: x / goodloc are the resident [N,G] matrices, batch row b = their row row_index[b].
+    dbias: fp32 [G], receives the column sums of dlogits (bias gradient of the layer that made the logits)."""
     L.require_gpu(logits, x, goodloc, dlogits)
     B, G = logits.shape
     assert x.shape[1] == G and goodloc.shape == x.shape and (row_index is not None or x.shape[0] == B)
@@ -402,6 +403,14 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
     assert ws.numel() >= recon_nb_ws(B, G, C) and sizefactor.dtype == torch.float32 and sizefactor.is_contiguous()
     if lgx1 is not None:
         assert lgx1.dtype == torch.float32 and lgx1.is_contiguous() and lgx1.numel() == B and lgx1.is_cuda
+    if dbias is not None:
+        assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == G and dbias.is_cuda
+        check(lib.c2_recon_nb_fwd_bwd_dbias(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"),
+                                            ptr(goodloc), _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta),
+                                            ptr(cond), C, B, G, float(inv_B), ptr(loss_out), ptr(dlogits),
+                                            dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws),
+                                            ptr(status), ptr(lgx1), ptr(row_index), ptr(dbias), stream()))
+        return
     check(lib.c2_recon_nb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"), ptr(goodloc),
                                   _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta), ptr(cond), C, B, G,
                                   float(inv_B), ptr(loss_out), ptr(dlogits), dt_code(dlogits.dtype),

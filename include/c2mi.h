@@ -150,7 +150,8 @@ int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64_t slab_str
  *   p = softmax(logits); mu = sizefactor*p; theta_b = exp(q_b . theta^T) with q_b the scatter-quirk
  *   vector of the multi-hot row; ll as losses.py:57-65; recon = -(1/Bn) sum goodloc*ll.
  * Adds recon to *loss_out; writes dlogits (dtype dl_dtype, unit upstream gradient) and dtheta [G,C].
- * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set non-zero if a cond value is outside [0,C).
+ * ws: c2_recon_nb_ws(B,G,C) floats.  status_dev: int32 word, set to 1 if a cond value is outside [0,C), to 2 if a
+ * dispersion exp(theta) is below 1e-17 or not a number (outside the loss kernel's arithmetic).
  * lgx1_rowsum: NULL, or [B] with sum_g goodloc*lgamma(x+1) of each row (c2_nb_row_const): that term of
  * losses.py:60-64 depends on the data only, so a resident dataset evaluates it once instead of every step.
  * row_index: NULL, or [B] int64: x and goodloc are then the RESIDENT matrices and row b of the batch is their row
@@ -162,6 +163,16 @@ int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_
                         int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
                         int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
                         const int64_t* row_index, void* stream);
+
+/* c2_recon_nb_fwd_bwd, and in the same pass dbias[g] = sum_b dlogits[b][g] (fp32, unit upstream gradient): the bias
+ * gradient of the Linear that produced the logits (modules.py:471-477, decoder.recon_decoder; autograd's column sum
+ * of the output gradient), taken from the values before they are rounded to dl_dtype.  The register-resident form of
+ * the loss kernel accumulates it beside the row walk; other shapes run a column-sum pass over dlogits. */
+int c2_recon_nb_fwd_bwd_dbias(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
+                              int64_t ldg, const float* sizefactor, const float* theta, const int64_t* cond, int C,
+                              int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
+                              int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
+                              const int64_t* row_index, float* dbias, void* stream);
 
 /* ZINB reconstruction loss, forward and backward (celligner2.py:286-296, losses.py:68-124): as the NB entry point
  * with a second logit matrix `pi` (decoder.dropout_decoder, modules.py:471-477) and its gradient dpi:

@@ -368,7 +368,9 @@ def test_recon_nb(B, G, C, multi, dl_dtype):
     loss2 = torch.zeros(1, device=DEV)
     dl2 = torch.empty(B, G, device=DEV, dtype=dl_dtype)
     dth2 = torch.empty(G, C, device=DEV)
-    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss2, dl2, dth2, ws, status, lgx1=lgx)
+    db2 = torch.empty(G, device=DEV)
+    ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss2, dl2, dth2, ws, status, lgx1=lgx, dbias=db2)
+    assert rel(db2, do64.sum(0)) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
     assert abs(loss2.item() - recon64) < 1e-4 * abs(recon64)
     assert rel(dl2, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
     assert rel(dth2, dth64) < 1e-4
@@ -406,12 +408,15 @@ def test_recon_nb_row_walks_at_19k_genes(regt, monkeypatch):
         dl = torch.empty(B, G, device=DEV, dtype=dl_dtype)
         dth = torch.empty(G, C, device=DEV)
         status = torch.zeros(1, device=DEV, dtype=torch.int32)
+        db = torch.empty(G, device=DEV)
         ops.recon_nb(T(o), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dth,
-                     torch.empty(ops.recon_nb_ws(B, G, C), device=DEV), status)
+                     torch.empty(ops.recon_nb_ws(B, G, C), device=DEV), status, dbias=db)
         assert status.item() == 0
         assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
         assert rel(dl, do64) < (1e-4 if dl_dtype == torch.float32 else 1e-2)
         assert rel(dth, dth64) < 1e-4
+        # the column sums of dlogits (bias gradient of the layer above): in-kernel (regt) or by the column-sum pass
+        assert rel(db, do64.sum(0)) < (1e-4 if (dl_dtype == torch.float32 or regt == "1") else 1e-2)
 
 
 def test_recon_nb_more_than_255_rows_per_workgroup():
