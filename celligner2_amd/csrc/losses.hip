@@ -1141,7 +1141,7 @@ extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
 
 // Workgroup size and chunks per thread of the fast kernel for G genes, or {0, 0}: the general kernel runs.
 struct NbFast { int nt, nv; };
-static NbFast nb_fast_shape(int64_t G, bool vec) {
+static NbFast nb_fast_shape(int64_t G, bool vec, int64_t B) {
     const size_t lds = (size_t)((G + 3) & ~int64_t(3)) * sizeof(float);
     if (!vec || 2 * lds + 256 > 160 * 1024) return {0, 0};  // two LDS rows must fit the CU (G <= 20 448)
     if (G <= 1024) return {128, 2};  // (the rolling prefetch needs at least two chunks)
@@ -1155,8 +1155,10 @@ static NbFast nb_fast_shape(int64_t G, bool vec) {
     // 411 us)
     // (same box, 4096 x 19000: 768 x 7 with theta re-read per row 238 us, 512 x 10 with theta and the accumulator in
     // registers 232 us; C2_NB_REGT=0 selects the former: A/B and tests)
+    // (a workgroup that walks a single row pays for loading theta and flushing the registers without using them twice:
+    // 27 against 22 us at B = 128, so the register form needs more rows than workgroups)
     const char* e = getenv("C2_NB_REGT");
-    if (e == nullptr || atoi(e) != 0) return {512, 10};
+    if (e == nullptr ? B > kNbMaxGroups : atoi(e) != 0) return {512, 10};
     return {768, 7};
 }
 
@@ -1188,7 +1190,7 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
         else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), l, st, a);                                        \
         return 0;                                                                                             \
     } while (0)
-    const NbFast f = nb_fast_shape(a.G, vec);
+    const NbFast f = nb_fast_shape(a.G, vec, a.B);
 #define NB_FC(NT, NV) if (f.nt == NT && f.nv == NV) NB_F(NT, NV)
     NB_FC(128, 2);
     NB_FC(256, 2);
@@ -1238,7 +1240,7 @@ static int recon_nb_run(const float* logits, int64_t ldl, const float* x, int64_
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags, nullptr};
     // the loss kernel forms the column sums itself in its register-resident form; otherwise a column-sum pass follows
-    const bool db_in_kernel = dbias && nb_fast_shape(G, vec).nt == 512;
+    const bool db_in_kernel = dbias && nb_fast_shape(G, vec, B).nt == 512;
     if (db_in_kernel) a.part_db = part_db;
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
