@@ -715,9 +715,22 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
             Wp[e >> 1][e & 1] = 0.f;
             if (jok && myPi[r] >= 0) dmin = fminf(dmin, d);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
-        const float dmin_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dmin)));
+        // wave minimum on DPP lane moves (six __shfl_xor steps are six dependent trips through the LDS crossbar, ~600
+        // cycles of a ~18k-cycle tile); lane 63 ends up with the minimum over the wave (EXEC is all ones here)
+        {
+#define C2_DPP_MIN(ctrl, rows)                                                                                   \
+    dmin = fminf(dmin, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dmin),       \
+                                                                             __builtin_bit_cast(int, dmin), ctrl, \
+                                                                             rows, 0xF, false)))
+            C2_DPP_MIN(0xB1, 0xF);   // quad_perm [1,0,3,2]
+            C2_DPP_MIN(0x4E, 0xF);   // quad_perm [2,3,0,1]
+            C2_DPP_MIN(0x141, 0xF);  // row_half_mirror
+            C2_DPP_MIN(0x140, 0xF);  // row_mirror
+            C2_DPP_MIN(0x142, 0xA);  // row_bcast15 into rows 1 and 3
+            C2_DPP_MIN(0x143, 0xC);  // row_bcast31 into rows 2 and 3
+#undef C2_DPP_MIN
+        }
+        const float dmin_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmin), 63));
         MMD_T(2)
         // beta_k = 1/(2 alpha_k) folded at compile time in fp32, as the reference forms it (losses.py:156);
         // exp(-beta d) = exp2(-beta log2(e) d) on v_exp_f32; terms in the reference's order
