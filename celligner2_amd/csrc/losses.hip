@@ -936,7 +936,7 @@ constexpr int kNbMaxGroups = C2_NB_GROUPS;
 // ---- ZINB (celligner2.py:286-296, losses.py:68-124): the NB kernel's row walk with a second logit matrix pi (dropout
 // head) and its gradient.  x < eps: ll = softplus(ptl) - softplus(-pi), ptl = -pi + theta (log(theta+eps) -
 // log(theta+mu+eps));  x > eps: ll = NB log-likelihood - pi - softplus(-pi).  Scalar accesses, four passes per row
-// (the row is re-read from L2): this is the option-matrix path, not the benchmarked one.
+// (the row is re-read from L2): the general form, for rows the fast kernel below does not take (unaligned, G > 20 480).
 struct ZinbExtra {
     const float* pi;
     void* dpi;
@@ -1053,6 +1053,249 @@ __global__ __launch_bounds__(NT) void zinb_fwd_bwd_kernel(NbArgs a, ZinbExtra z)
     }
 }
 
+// ---- ZINB fast path (16-byte aligned rows, G % 4 == 0, G <= 4 NT NV) ---------------------------------------------------
+// The NB fast kernel's shape without its hand-tuning: one workgroup walks whole rows, thread t owns genes 4(t + NT i)..+3
+// of chunk i in every row.  The row's logits (then exp(logit - max)) and p * dloss/dp stay in REGISTERS between the
+// passes, so every input byte is read once and every transcendental is taken once; the dispersion-gradient accumulator
+// of the workgroup sits in LDS at thread-private addresses (no barrier); chunk i + 1's inputs (counts, mask, dropout
+// logits, four table values) are requested before chunk i is evaluated; rows are addressed through buffer resources
+// (a lane past the last gene loads zeros, its stores are dropped).  Table: [3 patterns][4][Gp] = {theta,
+// log(theta + eps), K1, K2} (zinb_table_kernel; the padding holds theta = 1, 0, 0, 0).
+// Per gene: exp of the softmax + 1/(theta+mu+eps), log(theta+mu+eps), exp(-|pi|), log1p and reciprocal of it (softplus
+// and sigmoid of pi from ONE exponential) + the zero branch (sigmoid / softplus of ptl: exp, log, rcp; theta/(theta+eps))
+// + the count branch (log(mu+eps), its reciprocal, lgamma / digamma of x + theta with one shared shift, lgamma(x + 1)):
+// both branches are evaluated for every gene and selected -- a wave of 256 genes all but never holds only one kind.
+__global__ void zinb_table_kernel(const float* __restrict__ theta, int C, int64_t G, int64_t Gp, float* __restrict__ tab,
+                                  const int64_t* __restrict__ cond, int64_t B, int* __restrict__ rowflags) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t r = g; r < B; r += (int64_t)gridDim.x * blockDim.x) {
+        int f = 0;
+        for (int j = 0; j < C; ++j) {
+            const int64_t v = cond[r * C + j];
+            f |= (v == 0 ? 1 : 0) | (v == 1 ? 2 : 0) | (((v < 0) | (v > 1) | (v >= C)) ? 4 : 0);
+        }
+        rowflags[r] = f;
+    }
+    if (g >= Gp) return;
+    const bool pad = g >= G;
+    const float t0 = pad ? 0.f : theta[g * C + 0];
+    const float t1 = (pad || C < 2) ? 0.f : theta[g * C + 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float t = p == 0 ? t0 : (p == 1 ? t1 : t0 + t1);
+        const float th = expf(t);
+        const float lte = logf(th + 1e-8f);
+        tab[(p * 4 + 0) * Gp + g] = pad ? 1.f : th;
+        tab[(p * 4 + 1) * Gp + g] = pad ? 0.f : lte;
+        tab[(p * 4 + 2) * Gp + g] = pad ? 0.f : th * lte - lgamma_pos(th);
+        tab[(p * 4 + 3) * Gp + g] = pad ? 0.f : lte + th / (th + 1e-8f) - digamma_pos(th);
+    }
+}
+
+struct ZinbGene { float ll, dmu_mu, dth, dpi; };
+// one gene: mu = sizefactor * softmax, th / lte / k1 / k2 from the table, x the count, pv the dropout logit
+__device__ __forceinline__ ZinbGene zinb_gene(float mu, float th, float lte, float k1, float k2, float x, float pv) {
+    const float eps = 1e-8f;
+    const float tm = th + mu + eps;
+    const float rtm = frcp(tm), ltm = flog(tm);
+    // softplus(-pv), sigmoid(pv), sigmoid(-pv) from t = exp(-|pv|)
+    const float t = fexp(-fabsf(pv));
+    const float l1t = t < 2.44140625e-4f ? t - 0.5f * t * t : flog(1.0f + t);
+    const float r1 = frcp(1.0f + t);
+    const bool ppos = pv >= 0.f;
+    const float sig_p = ppos ? r1 : t * r1;   // sigmoid(pv)
+    const float sig_n = ppos ? t * r1 : r1;   // sigmoid(-pv)
+    const float sp = fmaxf(-pv, 0.f) + l1t;   // softplus(-pv)
+    // zero branch (x < eps): ll = softplus(ptl) - softplus(-pv), ptl = -pv + theta (log(theta+eps) - log(theta+mu+eps))
+    const float dl = lte - ltm;
+    const float ptl = fmaf(th, dl, -pv);
+    const float u = fexp(-fabsf(ptl));
+    const float l1u = u < 2.44140625e-4f ? u - 0.5f * u * u : flog(1.0f + u);
+    const float ru = frcp(1.0f + u);
+    const float sg = ptl >= 0.f ? ru : u * ru;  // sigmoid(ptl)
+    const float thr = th * rtm;
+    ZinbGene zr;
+    zr.ll = fmaxf(ptl, 0.f) + l1u - sp;
+    zr.dmu_mu = -sg * thr * mu;
+    zr.dth = sg * (dl + th * frcp(th + eps) - thr);
+    zr.dpi = sig_n - sg;
+    // count branch (x > eps): NB log-likelihood - pv - softplus(-pv)
+    const float zt = x + th;
+    float lg, dg;
+    lgam_digam_fast(zt, lg, dg);
+    const float mue = mu + eps;
+    ZinbGene ct;
+    ct.ll = k1 - zt * ltm + x * flog(mue) + lg - lgamma_fast(x + 1.0f) - pv - sp;
+    ct.dmu_mu = x * mu * frcp(mue) - zt * mu * rtm;
+    ct.dth = k2 - ltm - zt * rtm + dg;
+    ct.dpi = -sig_p;
+    const bool zero = x < eps, pos = x > eps;
+    ZinbGene o;
+    o.ll = zero ? zr.ll : (pos ? ct.ll : 0.f);
+    o.dmu_mu = zero ? zr.dmu_mu : (pos ? ct.dmu_mu : 0.f);
+    o.dth = zero ? zr.dth : (pos ? ct.dth : 0.f);
+    o.dpi = zero ? zr.dpi : (pos ? ct.dpi : 0.f);
+    return o;
+}
+
+template <typename TD, int NT, int NV>
+__global__ __launch_bounds__(NT) void zinb_rowreg_kernel(NbArgs a, ZinbExtra z) {
+    extern __shared__ __attribute__((aligned(16))) float dacc[];  // [NV][NT] chunks of four: d(theta) accumulator
+    __shared__ float red[32];
+    const int tid = threadIdx.x;
+    const int Gi = (int)a.G;
+    const int64_t Gp = nb_tab_ld(a.G);
+    f32x4* acc = reinterpret_cast<f32x4*>(dacc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur_pat = -1, flushed = 0, red_half = 0;
+    float loss_acc = 0.f;
+    auto flush = [&](int pat) {  // every thread owns its genes: no barrier
+        float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * a.G;
+        const bool first = !((flushed >> pat) & 1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * (tid + NT * i);
+            if (c < Gi) {
+                f32x4 v = acc[i * NT + tid];
+                if (!first) v += *reinterpret_cast<const f32x4*>(dst + c);
+                *reinterpret_cast<f32x4*>(dst + c) = v;
+                acc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        flushed |= 1 << pat;
+    };
+    constexpr unsigned kRsrcFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9)
+    auto row_rsrc = [&](const void* base, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+    };
+    const int v16 = tid * 16;
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, int i) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v16, i * NT * 16, 0));
+    };
+    const int always = Gi + 4 * NT * NV + 8;  // see nb_rowreg_kernel: real branches keep the chunks' temporaries apart
+    const float scale = -a.inv_B;
+    for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
+        const int fl = a.rowflags[row];
+        if ((fl & 4) || !(fl & 3)) {
+            if (tid == 0) *a.status = 1;
+            continue;
+        }
+        const int pat = (fl & 3) == 3 ? 2 : ((fl & 2) ? 1 : 0);
+        if (pat != cur_pat) {
+            if (cur_pat >= 0) flush(cur_pat);
+            cur_pat = pat;
+        }
+        const int64_t srow = a.ridx ? a.ridx[row] : row;
+        const auto ro = row_rsrc(a.logits + row * a.ldl, Gi * 4);
+        const auto rp = row_rsrc(z.pi + row * z.ldpi, Gi * 4);
+        const auto rx = row_rsrc(a.x + srow * a.ldx, Gi * 4);
+        const auto rg = row_rsrc(a.goodloc + srow * a.ldg, Gi);
+        const auto rt = row_rsrc(a.tab + (int64_t)pat * 4 * Gp, (int)(4 * Gp * 4));
+        const auto rdl = row_rsrc(reinterpret_cast<TD*>(a.dlogits) + row * a.lddl, Gi * (int)sizeof(TD));
+        const auto rdp = row_rsrc(reinterpret_cast<TD*>(z.dpi) + row * z.lddpi, Gi * (int)sizeof(TD));
+        const float sf = a.sizefactor[row];
+        f32x4 ev[NV], pg[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ev[i] = ld16(ro, i);
+        // inputs of a chunk: counts, dropout logits, mask, theta / log / K1 / K2
+        f32x4 qx, qp, q0, q1, q2, q3;
+        unsigned qm;
+        auto request = [&](int i) {
+            qx = ld16(rx, i);
+            qp = ld16(rp, i);
+            qm = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rg, tid * 4, i * NT * 4, 0);
+            q0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, v16, i * NT * 16, 0));
+            q1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, v16 + (int)(Gp * 4), i * NT * 16, 0));
+            q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, v16 + (int)(Gp * 8), i * NT * 16, 0));
+            q3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, v16 + (int)(Gp * 12), i * NT * 16, 0));
+        };
+        request(0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (4 * (tid + NT * i) >= Gi) ev[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            mx = fmaxf(fmaxf(mx, fmaxf(ev[i][0], ev[i][1])), fmaxf(ev[i][2], ev[i][3]));
+        }
+        mx = nb_block_reduce<true, NT>(mx, red, red_half);
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ev[i][k] = fexp(ev[i][k] - mx);
+                sm += ev[i][k];
+            }
+        }
+        sm = nb_block_reduce<false, NT>(sm, red, red_half);
+        const float inv_sum = 1.0f / sm;
+        const float cmu = sf * inv_sum;
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 cx = qx, cp = qp, c0 = q0, c1 = q1, c2 = q2, c3 = q3;
+            const unsigned cm = qm;
+            if (i + 1 < NV) request(i + 1);
+            if (4 * (tid + NT * i) < always) {
+                f32x4 dp4, dt4;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2 += 2) {
+                    if (4 * (tid + NT * i) + k2 < always) {  // (a branch per gene pair, for the same reason)
+#pragma unroll
+                        for (int k = k2; k < k2 + 2; ++k) {
+                            const bool m = (cm >> (8 * k)) & 0xffu;
+                            const ZinbGene gq = zinb_gene(ev[i][k] * cmu, c0[k], c1[k], c2[k], c3[k], cx[k], cp[k]);
+                            const float pgk = m ? scale * gq.dmu_mu : 0.f;
+                            pg[i][k] = pgk;
+                            S += pgk;
+                            dp4[k] = m ? scale * gq.dpi : 0.f;
+                            dt4[k] = m ? scale * c0[k] * gq.dth : 0.f;
+                            loss_acc += m ? gq.ll : 0.f;
+                        }
+                    }
+                }
+                acc[i * NT + tid] += dt4;
+                if (sizeof(TD) == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dp4), rdp, v16, i * NT * 16, 0);
+                    asm volatile("s_nop 1" ::: "memory");  // see nb_rowreg_kernel: store-data hazard
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    u32x2 pk;
+                    pk[0] = (unsigned)f2bf(dp4[0]) | ((unsigned)f2bf(dp4[1]) << 16);
+                    pk[1] = (unsigned)f2bf(dp4[2]) | ((unsigned)f2bf(dp4[3]) << 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rdp, tid * 8, i * NT * 8, 0);
+                }
+            }
+        }
+        S = nb_block_reduce<false, NT>(S, red, red_half);
+        const float pS = inv_sum * S;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = fmaf(-ev[i][k], pS, pg[i][k]);
+            if (sizeof(TD) == 4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), rdl, v16, i * NT * 16, 0);
+                asm volatile("s_nop 1" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                u32x2 pk;
+                pk[0] = (unsigned)f2bf(d[0]) | ((unsigned)f2bf(d[1]) << 16);
+                pk[1] = (unsigned)f2bf(d[2]) | ((unsigned)f2bf(d[3]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rdl, tid * 8, i * NT * 8, 0);
+            }
+        }
+    }
+    if (cur_pat >= 0) flush(cur_pat);
+    __syncthreads();
+    loss_acc = block_sum<NT>(loss_acc, red);
+    if (tid == 0) {
+        a.part_loss[blockIdx.x] = -a.inv_B * loss_acc;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.part_flag[blockIdx.x * 3 + p] = (flushed >> p) & 1;
+    }
+}
+
 // ---- MSE ---------------------------------------------------------------------------------------------------
 template <typename TD>
 __global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
@@ -1133,10 +1376,10 @@ using namespace c2;
 extern "C" size_t c2_recon_nb_ws(int64_t B, int64_t G, int C) {
     (void)C;
     const int64_t ng = std::min<int64_t>(std::max<int64_t>(B, 1), kNbMaxGroups);
-    // table 9G + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
+    // table 9G (12G: ZINB's fast kernel) + partial dtheta ng*3*G + flags ng*3 (as floats) + loss partials ng
     // ... + dtheta slices + the row classification (B ints)
     // ... + the workgroups' column sums of dlogits (c2_recon_nb_fwd_bwd_dbias)
-    return (size_t)(9 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 4 * G + B + 64 + ng * G + 64);
+    return (size_t)(12 * nb_tab_ld(G) + ng * 3 * G + ng * 3 + ng + 64 + (int64_t)kDthSlices * 4 * G + B + 64 + ng * G + 64);
 }
 
 // Workgroup size and chunks per thread of the fast kernel for G genes, or {0, 0}: the general kernel runs.
@@ -1160,6 +1403,19 @@ static NbFast nb_fast_shape(int64_t G, bool vec, int64_t B) {
     const char* e = getenv("C2_NB_REGT");
     if (e == nullptr ? B > kNbMaxGroups : atoi(e) != 0) return {512, 10};
     return {768, 7};
+}
+
+// ZINB fast kernel: 4 NT NV >= G (and <= the table's padded row, nb_tab_ld)
+static NbFast zinb_fast_shape(int64_t G, bool vec) {
+    if (!vec) return {0, 0};
+    if (G <= 1024) return {128, 2};
+    if (G <= 2048) return {256, 2};
+    if (G <= 4096) return {256, 4};
+    if (G <= 8192) return {512, 4};
+    if (G <= 12288) return {512, 6};
+    if (G <= 16384) return {512, 8};
+    if (G <= 20480) return {512, 10};
+    return {0, 0};
 }
 
 template <typename TD>
@@ -1295,15 +1551,48 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     if (B == 0 || G == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = (int)std::min<int64_t>(B, kNbMaxGroups);
+    const int64_t Gp = nb_tab_ld(G);
+    const bool vec = (G % 4 == 0) && (ldl % 4 == 0) && (ldpi % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) &&
+                     (lddl % 4 == 0) && (lddpi % 4 == 0) && aligned16(logits) && aligned16(pi) && aligned16(x) &&
+                     aligned16(dlogits) && aligned16(dpi) && (((uintptr_t)goodloc & 3) == 0) && aligned16(ws);
+    const NbFast f = zinb_fast_shape(G, vec);
     float* tab = ws;
-    float* part_dt = tab + 9 * nb_tab_ld(G);
+    float* part_dt = tab + (f.nt ? 12 : 9) * Gp;
     int* part_flag = reinterpret_cast<int*>(part_dt + (int64_t)ngroups * 3 * G);
     float* part_loss = reinterpret_cast<float*>(part_flag + ngroups * 3);
+    ZinbExtra z{pi, dpi, ldpi, lddpi};
+    if (f.nt) {
+        int* rowflags = reinterpret_cast<int*>(part_loss + ngroups + 32 + (int64_t)kDthSlices * 4 * G) + 16;
+        hipLaunchKernelGGL(zinb_table_kernel, dim3((unsigned)(Gp / 256)), dim3(256), 0, st, theta, C, G, Gp, tab, cond, B,
+                           rowflags);
+        NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
+                 nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags, nullptr};
+#define ZINB_F(NT, NV)                                                                                        \
+    if (f.nt == NT && f.nv == NV) {                                                                           \
+        const size_t l = (size_t)NT * NV * 16;                                                                \
+        if (d_dtype == C2_BF16) {                                                                             \
+            auto k = zinb_rowreg_kernel<bf16_t, NT, NV>;                                                       \
+            if (l > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+            hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), l, st, a, z);                                       \
+        } else {                                                                                              \
+            auto k = zinb_rowreg_kernel<float, NT, NV>;                                                        \
+            if (l > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+            hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), l, st, a, z);                                       \
+        }                                                                                                     \
+    }
+        ZINB_F(128, 2)
+        ZINB_F(256, 2)
+        ZINB_F(256, 4)
+        ZINB_F(512, 4)
+        ZINB_F(512, 6)
+        ZINB_F(512, 8)
+        ZINB_F(512, 10)
+#undef ZINB_F
+    } else {
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
                        (const int64_t*)nullptr, (int64_t)0, (int*)nullptr, (int32_t*)nullptr);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
              nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
-    ZinbExtra z{pi, dpi, ldpi, lddpi};
     const size_t lds = (size_t)G * sizeof(float);
     constexpr int NT = 512;
     if (d_dtype == C2_BF16) {
@@ -1314,6 +1603,7 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
         auto k = zinb_fwd_bwd_kernel<float, NT>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), lds, st, a, z);
+    }
     }
     float* part2 = part_loss + ngroups + 32;
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,

@@ -738,15 +738,19 @@ def test_wgrad_two_part_schedule(by_rows):
                                    torch.empty((256 * 4, K) if by_rows else (N, 256 * 4), device=DEV), None)
 
 
-@pytest.mark.parametrize("B,G,C,multi", [(6, 200, 2, True), (4, 3001, 3, False), (3, 19000, 2, False)])
+@pytest.mark.parametrize("B,G,C,multi", [(6, 200, 2, True), (4, 3001, 3, False), (3, 19000, 2, False), (5, 1500, 2, True),
+                                         (4, 4000, 3, False), (3, 8000, 2, True), (3, 12000, 3, False),
+                                         (2, 16000, 2, False), (2, 20480, 2, False), (2, 20484, 2, False)])
 @pytest.mark.parametrize("d_dtype", [torch.float32, torch.bfloat16])
 def test_recon_zinb(B, G, C, multi, d_dtype):
-    """c2_recon_zinb_fwd_bwd vs the oracle (pinned to the reference by tests/golden/zinb_mmd_z.npz)."""
+    """c2_recon_zinb_fwd_bwd vs the oracle (pinned to the reference by tests/golden/zinb_mmd_z.npz): every instance of the
+    fast kernel (G % 4 == 0, up to 20 480 genes) and the general kernel (odd G, G beyond the fast kernel)."""
     ops = _ops()
     rng = np.random.default_rng(G + B)
     o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C, multi)
     x[:, ::3] = 0.0  # plenty of zeros: the zero-inflation branch
     pi = rng.standard_normal((B, G)).astype(np.float32) * 2
+    pi[:, 5::7] *= 6.0  # saturated dropout logits: exp(-|pi|) below the log1p series switch
     recon64, do64, dpi64, dth64 = orc.zinb_loss(o.astype(np.float64), pi.astype(np.float64), x.astype(np.float64), good,
                                                 sf.astype(np.float64), theta.astype(np.float64), cond)
     loss = torch.zeros(1, device=DEV)
@@ -761,6 +765,45 @@ def test_recon_zinb(B, G, C, multi, d_dtype):
     tol = 1e-4 if d_dtype == torch.float32 else 1e-2
     assert rel(dl, do64) < tol and rel(dpi, dpi64) < tol
     assert rel(dth, dth64) < 1e-4
+    # the same batch read through a row index from a larger resident matrix: bit-identical
+    perm = rng.permutation(B + 3)[:B]
+    xf = rng.poisson(3.0, (B + 3, G)).astype(np.float32)
+    gf = rng.uniform(size=(B + 3, G)) > 0.5
+    xf[perm], gf[perm] = x, good
+    loss2 = torch.zeros(1, device=DEV)
+    dl2, dpi2, dth2 = torch.empty_like(dl), torch.empty_like(dpi), torch.empty_like(dth)
+    ops.recon_zinb(T(o), T(pi), T(xf), T(gf), T(sf), T(theta), T(cond), 1.0 / B, loss2, dl2, dpi2, dth2, ws, status,
+                   row_index=T(perm.astype(np.int64)))
+    assert loss2.item() == loss.item()
+    assert torch.equal(dl2, dl) and torch.equal(dpi2, dpi) and torch.equal(dth2, dth)
+
+
+def test_recon_zinb_row_walk_and_bad_rows():
+    """Several rows per workgroup with the row pattern changing inside a walk (the LDS accumulator is flushed per pattern),
+    a tenth of the entries masked; then a condition value outside {0, 1} raises the status word."""
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    B, G, C = 700, 2400, 2
+    o, x, good, sf, theta, cond = _nb_inputs(rng, B, G, C, multi=True)
+    good &= rng.uniform(size=(B, G)) > 0.1
+    cond[rng.integers(0, B, 40), :] = 1
+    cond[rng.integers(0, B, 40), :] = 0
+    x[:, 1::2] = 0.0
+    pi = rng.standard_normal((B, G)).astype(np.float32) * 2
+    recon64, do64, dpi64, dth64 = orc.zinb_loss(o.astype(np.float64), pi.astype(np.float64), x.astype(np.float64), good,
+                                                sf.astype(np.float64), theta.astype(np.float64), cond)
+    loss = torch.zeros(1, device=DEV)
+    dl, dpi = torch.empty(B, G, device=DEV), torch.empty(B, G, device=DEV)
+    dth = torch.empty(G, C, device=DEV)
+    ws = torch.empty(ops.recon_nb_ws(B, G, C), device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.recon_zinb(T(o), T(pi), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dpi, dth, ws, status)
+    assert status.item() == 0
+    assert abs(loss.item() - recon64) < 1e-4 * abs(recon64)
+    assert rel(dl, do64) < 1e-4 and rel(dpi, dpi64) < 1e-4 and rel(dth, dth64) < 1e-4
+    cond[17, 0] = 3
+    ops.recon_zinb(T(o), T(pi), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss, dl, dpi, dth, ws, status)
+    assert status.item() == 1
 
 
 @pytest.mark.parametrize("M,N,K,nslab", [(2104, 1024, 2312, 1), (4096, 1024, 19000, 4), (2304, 1280, 4096, 2)])
