@@ -167,7 +167,17 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     comm = None
-    if world > 1:
+    # C2_DP_SINGLE_RANK=1 with --gpus 1: the data-parallel pipeline (no graph, bucket exchange on the side stream, sharded
+    # Adam, parameter all-gather) with ONE rank over RCCL -- a rehearsal of the N > 1 code path on a one-GPU box; the line
+    # it prints says "parallelism": "dp1-rehearsal"
+    rehearse = world == 1 and backend == "nccl" and os.environ.get("C2_DP_SINGLE_RANK") == "1"
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dp = world > 1 or rehearse
+    if dp:
         # "nccl" (= RCCL) is the product path; C2_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed with several
         # ranks sharing one GPU (RCCL needs one device per rank)
         if backend == "nccl":
@@ -203,7 +213,7 @@ def main():
     data = synth_dataset(cfg, device)
     # one GPU: the step is replayed as a HIP graph unless --graph 0; ranks of a data-parallel run launch it kernel by kernel
     # (the gradient exchange is not capturable)
-    use_graph = (bool(cfg.get("graph", True)) if args.graph < 0 else bool(args.graph)) and world == 1
+    use_graph = (bool(cfg.get("graph", True)) if args.graph < 0 else bool(args.graph)) and not dp
     trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=Bglob, use_leiden=False,
                                 alpha_kl=1e-3, monitor=False, use_early_stopping=False, rng="device", world=comm,
                                 seed=2020, n_samples=n_samples, **({"graph": True} if use_graph else {}))
@@ -229,15 +239,17 @@ def main():
         trainer.on_iteration(b)
 
     def sync():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
+
+    t_start = time.perf_counter()
 
     def trace(msg):  # C2_BENCH_TRACE=1: stage markers on stderr (rehearsals of the multi-rank path)
         if os.environ.get("C2_BENCH_TRACE"):
             import faulthandler
             faulthandler.dump_traceback_later(60, exit=True)  # re-armed at every marker: fires only on a stall
-            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+            print(f"[bench rank {rank} t={time.perf_counter() - t_start:9.4f}] {msg}", file=sys.stderr, flush=True)
 
     def timed(n, src, host=False):
         """n steps between two (barrier + device sync) points: (seconds, rows of this rank, host launch seconds)."""
@@ -253,7 +265,7 @@ def main():
 
     def over_ranks(dt, rows):
         """MAX of the time, SUM of the rows over ranks."""
-        if world == 1:
+        if not dp:
             return dt, rows
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         r = torch.tensor([rows], device=device, dtype=torch.int64)
@@ -262,6 +274,13 @@ def main():
         return float(t.item()), int(r.item())
 
     trace("model, dataset and trainer built")
+    # The objects built so far (modules, the dataset's tensors, everything imported) are permanent: keep the cyclic
+    # collector from walking them in the loop.  A step launched kernel by kernel creates a few thousand short-lived Python
+    # objects, and a full collection over the whole heap -- measured as a 70-100 ms stall of the launch thread once in
+    # ~25 steps of the data-parallel pipeline -- costs more than 30 steps.
+    import gc
+    gc.collect()
+    gc.freeze()
     if use_graph:  # set-up, like building the model: two ordinary steps, then the step that captures the graph
         for _ in range(3):
             step(stream)
@@ -294,11 +313,11 @@ def main():
         if rank == 0:
             print(json.dumps({"profile_pass": True, "steps": args.steps, "warmup": args.warmup, "hip_graph": use_graph,
                               "ms_per_step": 1e3 * dt / args.steps, "value": cells / dt}))
-        if world > 1:
+        if dp:
             dist.destroy_process_group()
         return
     n_steady = max(args.steps, int(np.ceil(args.steady_seconds / max(dt / args.steps, 1e-6))))
-    if world > 1:  # every rank must run the same number of steps
+    if dp:  # every rank must run the same number of steps
         ns = torch.tensor([n_steady], device=device, dtype=torch.int64)
         dist.all_reduce(ns, op=dist.ReduceOp.MAX)
         n_steady = int(ns.item())
@@ -318,7 +337,7 @@ def main():
         timed(args.steps, eager)
         prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
     all_in_step = None
-    if world == 1:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
+    if not dp:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
         ld = trainer.dataloader_train
         ld.nb_const, ld.resident_xin = False, (lambda n: False)
         stream2 = batches()
@@ -332,7 +351,7 @@ def main():
         faulthandler.cancel_dump_traceback_later()
     last = losses_seen + [float(v[-1]) for k, v in sorted(trainer.iter_logs.items())]
     assert all(np.isfinite(last)), f"non-finite losses {last}"
-    n_gpus = dist.get_world_size() if world > 1 else 1
+    n_gpus = dist.get_world_size() if dp else 1
 
     if rank == 0:
         gemm_ms = sum(s.elapsed_time(e) for _, s, e in prof)
@@ -356,7 +375,7 @@ def main():
             "cells_timed": cells,
             "config": {"workload": f"{args.config}: {cfg['desc']}; {B} cells/GPU/step, global batch {Bglob}, "
                                    f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
-                       "global_batch": Bglob, "parallelism": f"dp{n_gpus}", "backend": backend if world > 1 else None,
+                       "global_batch": Bglob, "parallelism": f"dp{n_gpus}" + ("-rehearsal" if rehearse else ""), "backend": backend if dp else None,
                        "epoch_rows": n_samples, "hip_graph": use_graph,
                        "optimizer": ("sharded over ranks (reduce-scatter, Adam on own chunks, all-gather)"
                                      if (comm is not None and comm.sharded) else "every rank updates every parameter"),
@@ -374,10 +393,10 @@ def main():
                          "gemm_ms_per_step": gemm_ms / args.steps, "gemm_flops_per_step": gemm_flops / args.steps,
                          "gemm_flops_per_step_expected": 5 * 2.0 * B * cfg["G"] * H1},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dp:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,7 @@ class StepEngine:
         self._touched = set()
         self.world_size, self.rank = 1, 0
         self.comm = None  # set by parallel.DataParallelStep
+        self.exchange = False  # collectives are issued: more than one rank (or the single-rank RCCL rehearsal)
         self.bn = dict(bn_modules or {})
         self.use_bn = bool(cfg.get("use_bn"))
         nh = len(cfg["hidden"])
@@ -165,7 +166,7 @@ class StepEngine:
         multiple of 64 x world_size, so that it cuts into equal 256-byte-aligned chunks, one per rank, and the trainable
         parameters themselves become views of a second flat buffer with the SAME offsets (`param_flat`): the bucket is
         reduce-scattered, each rank runs Adam on its chunk, and the chunk is all-gathered in place."""
-        sharded = self.comm is not None and getattr(self.comm, "sharded", False) and self.world_size > 1
+        sharded = self.exchange and getattr(self.comm, "sharded", False)
         key = (tuple((n, tuple(p.shape), p.requires_grad) for n, p in self.p.items()), sharded, self.world_size)
         if getattr(self, "_arena_key", None) == key:
             return
@@ -218,7 +219,7 @@ class StepEngine:
         return self.grad[name]
 
     def _reduce_bucket(self, i):
-        if self.comm is not None and self.world_size > 1:
+        if self.exchange:
             lo, hi = self.buckets[i]
             if hi > lo:
                 self.comm.reduce_bucket_async(self.grad_flat[lo:hi])
@@ -530,7 +531,7 @@ class StepEngine:
         parts, total = None, B
         if train:
             parts = part
-            if self.comm is not None and self.world_size > 1:
+            if self.exchange:
                 parts = self.comm.allgather_stats(part[0])
                 total = B * self.world_size
         self._bn_total = getattr(self, "_bn_total", {})
@@ -592,7 +593,7 @@ class StepEngine:
                           self.gbuf(gn) if self.p[gn].requires_grad else None,
                           self.gbuf(bn_) if self.p[bn_].requires_grad else None,
                           self.buf(f"bn.ws.{B}x{H}", (ops.bn_ws(B, H),)), extra=extra, extra_scale=extra_scale)
-        if batch_stats and self.comm is not None and self.world_size > 1:
+        if batch_stats and self.exchange:
             self.comm.allreduce_scalars(sums)  # dgamma / dbeta above stay local sums: the arena all-reduce adds them
         ops.bn_bwd(dy, self._ws[blk.name + ".yhat"], sums, total, batch_stats, gamma, self._ws[blk.name + ".bnstats"],
                    dh, planes=planes)
@@ -731,7 +732,7 @@ class StepEngine:
         if cfg["use_mmd"]:
             feat = z32 if cfg["mmd_on"] == "z" else y1
             D = feat.shape[1]
-            if self.comm is not None and self.world_size > 1:
+            if self.exchange:
                 feat_all, cond_all = self.comm.allgather_rows(feat, cond)
                 row0 = self.rank * B
             else:
@@ -744,7 +745,7 @@ class StepEngine:
             ws = self.buf("mmd.ws", (ops.mmd_ws(B, Bg, D),))
             ops.mmd(feat_all, part, wt, row0, B, cfg["beta"], losses[2:3], dfeat, ws)
             self._dfeat = dfeat
-        if self.comm is not None and self.world_size > 1:
+        if self.exchange:
             self.comm.allreduce_scalars(losses)  # every term is already normalised by the GLOBAL batch
         return losses
 

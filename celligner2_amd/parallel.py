@@ -26,6 +26,8 @@ Two forms of the exchange:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,7 +38,11 @@ class DataParallelStep:
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self._setup(dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group) != "nccl")
-        self.sharded = bool(shard_optimizer) and self.world_size > 1
+        # C2_DP_SINGLE_RANK=1 (tests): a one-rank group still issues every collective -- the only way to run the RCCL
+        # branch (stream-ordered exchange on the side stream, reduce-scatter / all-gather through the staging chunk) on a
+        # box with one GPU.  Otherwise one rank exchanges nothing.
+        self.active = self.world_size > 1 or os.environ.get("C2_DP_SINGLE_RANK") == "1"
+        self.sharded = bool(shard_optimizer) and self.active
 
     def _setup(self, world_size, rank, host_backend):
         self.world_size, self.rank = world_size, rank
@@ -49,6 +55,7 @@ class DataParallelStep:
         self.defer_last = False  # set by the optimizer wiring: the last bucket's wait moves into FusedAdam.step
         self._deferred = None    # (event, first byte, one-past-last byte) of the bucket still being reduced
         self.sharded = False
+        self.active = world_size > 1
         self._arena = None       # (gradient arena, flat parameter buffer, buckets) of the attached engine (sharded form)
 
     # -- wiring
@@ -60,6 +67,7 @@ class DataParallelStep:
         engine.comm = self
         engine.world_size = self.world_size
         engine.rank = self.rank
+        engine.exchange = self.active
 
     def shard(self, n_global):
         """Rows of a global batch owned by this rank (contiguous, equal shares; remainder to the last ranks)."""

@@ -152,7 +152,12 @@ class _Loader:
                 idx = torch.randperm(len(self.ds), generator=g)
             return idx.to(dev)
         if self.weights is not None:
-            return torch.multinomial(self.weights.to(dev), self.num_samples, True)
+            # the weights go to the device once: a copy from pageable host memory per epoch would hold the launch thread
+            # until the GPU has drained everything queued before it
+            w = self.__dict__.get("_weights_dev")
+            if w is None or w.device != dev:
+                w = self.__dict__["_weights_dev"] = self.weights.to(dev)
+            return torch.multinomial(w, self.num_samples, True)
         return torch.randperm(len(self.ds), device=dev)
 
     def __iter__(self):

@@ -17,9 +17,16 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    # C2_DDP_BACKEND=nccl with ONE rank (and C2_DP_SINGLE_RANK=1, so that the rank still issues every collective): the RCCL
+    # branch of parallel.py -- stream-ordered exchange on the side stream, deferred last bucket, reduce-scatter and
+    # all-gather through the staging chunk -- on the one GPU there is.
+    backend = os.environ.get("C2_DDP_BACKEND", "gloo")
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     from celligner2_amd.model import Celligner2
     from celligner2_amd.parallel import DataParallelStep
     from oracle import c2_oracle as orc
@@ -81,6 +88,7 @@ def main():
     per = B // world
     losses, grads = run(m, slice(rank * per, (rank + 1) * per), sync=comm)
     assert comm.defer_last and comm.deferred_range() is None
+    assert comm._host_backend == (backend != "nccl") and m._engine().exchange
     if shard:
         eng = m._engine()
         assert comm.sharded and eng.param_flat is not None
@@ -111,7 +119,7 @@ def main():
                 ok = False
                 print("MISMATCH param after Adam", n, err)
         print("losses ddp", losses, "single", ref_l)
-    flag = torch.tensor([1.0 if ok else 0.0])
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 1.0 else 1)

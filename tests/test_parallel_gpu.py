@@ -16,3 +16,16 @@ def test_two_ranks_equal_single_process(variant):
            "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("variant", ["ln", "bn", "shard", "shard_bf16"])
+def test_one_rank_over_rccl_issues_every_collective(variant):
+    """The RCCL branch of parallel.py on the one GPU of the box: a one-rank "nccl" group with C2_DP_SINGLE_RANK=1 still
+    all-gathers the latent codes / BatchNorm partials, reduces (or reduce-scatters) every gradient bucket on the side
+    stream with the last one deferred into the optimizer, and all-gathers the parameter chunks -- real RCCL calls,
+    stream-ordered, on device tensors.  The result must equal the plain single-process step."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2_DDP_BACKEND="nccl", C2_DP_SINGLE_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
