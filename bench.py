@@ -38,6 +38,15 @@ CONFIGS = {
                desc="synthetic 100k x 19k, hidden [1024,512], latent 64, NB + MMD, 3 conditions"),
     "c2": dict(G=19000, hidden=[256, 128], latent=16, C=2, P=30, cls_hidden=[32, 64], B=128, N=11400, beta=500.0,
                desc="CCLE+TCGA shape 11.4k x 19k, hidden [256,128], latent 16, NB + MMD + classifier"),
+    # the other configurations of SURVEY.md 8(d): records kept under profiles/, not the headline
+    "c1": dict(G=1000, hidden=[128, 128], latent=10, C=5, P=0, cls_hidden=[32], B=128, N=15681, beta=1.0, recon="mse",
+               desc="pancreas shape 15.7k x 1000, hidden [128,128], latent 10, MSE on log1p counts + MMD, 5 conditions"),
+    "c3": dict(G=19000, hidden=[820, 512, 256], latent=26, C=3, P=30, cls_hidden=[32, 64], B=4096, N=30000, beta=1.0,
+               desc="GTEx+TCGA+CCLE shape 30k x 19k, hidden [820,512,256], latent 26, NB + MMD + classifier, 3 conditions"),
+    "c5": dict(G=19000, hidden=[256, 128], latent=16, C=3, P=30, cls_hidden=[32, 64], B=128, N=1000, beta=500.0,
+               dr=0.0, surgery=True,
+               desc="surgery fine-tune: the c2 model with a third condition, 1000 query rows, freeze + freeze_expression "
+                    "(trainable: theta and the condition columns), no dropout"),
 }
 
 
@@ -64,7 +73,10 @@ def synth_dataset(cfg, device, seed=2020):
         pred = torch.zeros(N, P, dtype=torch.int64, device=device)
         pred[torch.arange(N, device=device), pl] = 1
         pred[torch.rand(N, device=device, generator=g) < 0.2] = -1
-    return DeviceDataset.from_tensors(X, X.sum(1), good, cond, pred, minweight=0.2)
+    sf = X.sum(1)
+    if cfg.get("recon") == "mse":  # the MSE configurations feed log-transformed expression
+        X = torch.log1p(X)
+    return DeviceDataset.from_tensors(X, sf, good, cond, pred, minweight=0.2)
 
 
 def _cpu_model():
@@ -84,7 +96,7 @@ def cpu_baseline(cfg, seconds=25.0, warm=3, timed=20):
     Bc = 256
     ocfg = orc.Cfg(input_dim=cfg["G"], hidden_layer_sizes=cfg["hidden"], latent_dim=cfg["latent"],
                    n_conditions=cfg["C"], n_predictors=cfg["P"], classifier_hidden_layer_sizes=cfg["cls_hidden"],
-                   recon_loss="nb", use_mmd=True, beta=cfg["beta"])
+                   recon_loss=cfg.get("recon", "nb"), use_mmd=True, beta=cfg["beta"])
     rng = np.random.default_rng(0)
     params = orc.init_params(ocfg, 0, np.float32)
     x = rng.poisson(rng.uniform(0.5, 2, (Bc, 1)) * np.exp(rng.normal(1.5, 1.5, (1, cfg["G"])))).astype(np.float32)
@@ -135,6 +147,8 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="cells per GPU per step (default: the config's)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: cells per step over all GPUs, each rank takes 1/N (SURVEY.md 8(d): 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-pass", action="store_true",
                     help="warm-up and the K timed steps only (no steady-state loop, no all-terms leg, no CPU baseline): "
@@ -198,6 +212,11 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            print(f"bench.py: --global-batch {args.global_batch} does not divide over {world} ranks", file=sys.stderr)
+            sys.exit(2)
+        cfg["B"] = args.global_batch // world
     B = cfg["B"]
     Bglob = B * world
     # every batch of an epoch is a full global batch: the loader keeps a short last batch (as the reference's does), which
@@ -207,9 +226,14 @@ def main():
         print(f"bench.py: global batch {Bglob} exceeds the dataset ({cfg['N']} rows)", file=sys.stderr)
         sys.exit(2)
     torch.manual_seed(2020)
-    model = Celligner2(cfg["G"], cfg["hidden"], cfg["latent"], 0.05, False, "nb", conditions=[f"c{i}" for i in range(cfg["C"])],
+    recon = cfg.get("recon", "nb")
+    model = Celligner2(cfg["G"], cfg["hidden"], cfg["latent"], cfg.get("dr", 0.05), False, recon,
+                       conditions=[f"c{i}" for i in range(cfg["C"])],
                        use_mmd=True, mmd_on="z", beta=cfg["beta"], predictors=[f"p{i}" for i in range(cfg["P"])],
                        classifier_hidden_layer_sizes=cfg["cls_hidden"], precision=args.precision)
+    if cfg.get("surgery"):
+        from celligner2_amd.surgery import apply_freeze
+        apply_freeze(model.to(device), freeze_expression=True)
     data = synth_dataset(cfg, device)
     # one GPU: the step is replayed as a HIP graph unless --graph 0; ranks of a data-parallel run launch it kernel by kernel
     # (the gradient exchange is not capturable)
@@ -337,7 +361,7 @@ def main():
         timed(args.steps, eager)
         prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
     all_in_step = None
-    if not dp:  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
+    if not dp and recon == "nb":  # (single GPU only: the scaling runs time the headline pipeline and nothing else)
         ld = trainer.dataloader_train
         ld.nb_const, ld.resident_xin = False, (lambda n: False)
         stream2 = batches()
@@ -367,14 +391,16 @@ def main():
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         H1 = cfg["hidden"][0]
         out = {
-            "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes",
+            "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes" if cfg["G"] == 19000 else
+                      f"training cells/sec (fwd+bwd+Adam) at {cfg['G']} genes",
             "value": cells / dt, "unit": "cells/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "host_ms_per_step": 1e3 * t_host / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "cells_timed": cells,
             "config": {"workload": f"{args.config}: {cfg['desc']}; {B} cells/GPU/step, global batch {Bglob}, "
-                                   f"dataset resident in HBM, gene-width GEMMs {args.precision} operands fp32 accumulate",
+                                   f"dataset resident in HBM, {recon.upper()} reconstruction, gene-width GEMMs {args.precision} operands "
+                                   f"fp32 accumulate",
                        "global_batch": Bglob, "parallelism": f"dp{n_gpus}" + ("-rehearsal" if rehearse else ""), "backend": backend if dp else None,
                        "epoch_rows": n_samples, "hip_graph": use_graph,
                        "optimizer": ("sharded over ranks (reduce-scatter, Adam on own chunks, all-gather)"
@@ -391,7 +417,9 @@ def main():
                          "timed_in": "the K timed steps" if not use_graph else "the same K steps launched without the graph",
                          "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
                          "gemm_ms_per_step": gemm_ms / args.steps, "gemm_flops_per_step": gemm_flops / args.steps,
-                         "gemm_flops_per_step_expected": 5 * 2.0 * B * cfg["G"] * H1},
+                         # (gene-width = a weight dimension >= 2048; the frozen surgery step has no gene-width weight gradient)
+                         "gemm_flops_per_step_expected": ((3 if cfg.get("surgery") else 5) * 2.0 * B * cfg["G"] * H1
+                                                          if cfg["G"] >= 2048 else 0.0)},
         }
         if not args.no_cpu_baseline and not dp:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -113,7 +113,7 @@ class StepEngine:
     # ------------------------------------------------------------------ buffers
     KEEP_SHAPES = 4  # train / validation batches, each full-size and short
 
-    def buf(self, key, shape, dtype=F32):
+    def buf(self, key, shape, dtype=F32, zero=False):
         """The scratch tensor `key` in this shape: self._ws[key] afterwards.  Every key keeps its KEEP_SHAPES most
         recently used shapes, so alternating batch sizes (the short last batch of an epoch, validation) do not free and
         re-allocate the workspace twice per epoch -- and a step captured as a HIP graph for one batch size keeps its
@@ -125,7 +125,7 @@ class StepEngine:
         slot = (tuple(int(s) for s in shape), dtype)
         t = shapes.get(slot)
         if t is None:
-            t = shapes[slot] = torch.empty(slot[0], dtype=dtype, device=self.dev)
+            t = shapes[slot] = (torch.zeros if zero else torch.empty)(slot[0], dtype=dtype, device=self.dev)
             if len(shapes) > self.KEEP_SHAPES:
                 shapes.popitem(last=False)
         else:
@@ -134,6 +134,27 @@ class StepEngine:
         if self.recorded is not None:
             self.recorded.append(t)
         return t
+
+    def abuf(self, key, shape, dtype):
+        """A [B, H] activation that a gene-width GEMM may read as a bf16 operand.  The LDS-DMA kernels move 16-byte chunks
+        from 16-byte-aligned rows, so a 2-byte matrix whose width is not a multiple of 8 (the reference's own
+        hidden_layer_sizes=[820, 512, 256]) gets a leading dimension rounded up to 8 elements; the pad columns are zeroed
+        once, when the buffer is made, and never written again (the layer tails write H columns), so a reduction over
+        the padded width adds exact zeros.  Returns the [B, H] view."""
+        B, H = shape
+        if dtype == F32 or H % 8 == 0:
+            return self.buf(key, shape, dtype)
+        t = self.buf(key, (B, (H + 7) // 8 * 8), dtype, zero=True)
+        v = self._ws[key] = t[:, :H]
+        return v
+
+    @staticmethod
+    def _padded_width(t):
+        """Row stride of a 2-byte [rows, cols] view made by abuf / weight() over a zero-padded buffer, else 0."""
+        if t.dim() == 2 and t.element_size() == 2 and t.shape[1] % 8 and t.stride(1) == 1 and \
+                t.stride(0) == (t.shape[1] + 7) // 8 * 8:
+            return t.stride(0)
+        return 0
 
     def _readiness_order(self):
         """Parameter names in the order the backward pass finishes their gradients."""
@@ -233,11 +254,21 @@ class StepEngine:
             return p.detach()
         sh = self._shadow.get(name)
         if sh is None or sh.shape != p.shape:
-            sh = torch.empty(p.shape, dtype=torch.bfloat16, device=self.dev)
+            if p.dim() == 2 and p.shape[1] % 8:
+                # rows of a width that is not a multiple of 8 elements: leading dimension rounded up, pad zeroed once
+                # (see abuf); this copy is converted here, after every optimizer step, not inside the Adam kernel
+                # (which addresses a contiguous copy): shadow_for_adam() does not hand it out
+                ldp = (p.shape[1] + 7) // 8 * 8
+                sh = torch.zeros((p.shape[0], ldp), dtype=torch.bfloat16, device=self.dev)[:, :p.shape[1]]
+            else:
+                sh = torch.empty(p.shape, dtype=torch.bfloat16, device=self.dev)
             self._shadow[name] = sh
             self._shadow_ver[name] = None
         if self._shadow_ver[name] != p._version:
-            ops.cast_bf16(p.detach(), sh)
+            if sh.is_contiguous():
+                ops.cast_bf16(p.detach(), sh)
+            else:
+                ops.prep_input(p.detach(), sh, False)
             self._shadow_ver[name] = p._version
         return sh
 
@@ -249,7 +280,7 @@ class StepEngine:
             return None
         sh = self._shadow.get(name)
         if sh is not None:
-            return sh
+            return sh if sh.is_contiguous() else None  # (a padded copy is refreshed by weight(), see there)
         c = self._wplanes.get(name)
         if c is not None:
             return c[1]
@@ -384,6 +415,10 @@ class StepEngine:
     def _fwd(self, a, wname, y, bias=None):
         """y = a @ W^T (+ bias), unsplit."""
         w = self.weight(wname)
+        la, lw = self._padded_width(a), self._padded_width(w)
+        if la and la == lw:  # both zero-padded along the reduction: reduce over the padded width (16-byte chunks)
+            a = a.as_strided((a.shape[0], la), (la, 1), a.storage_offset())
+            w = w.as_strided((w.shape[0], lw), (lw, 1), w.storage_offset())
         a2, w2, _ = self._pair(a, w, a.shape[0], w.shape[0], w.shape[1], wy=wname)
         ops.linear_fwd(a2, w2, y, bias=bias, x3=self.x3)
 
@@ -483,7 +518,7 @@ class StepEngine:
         B = a.shape[0] if not isinstance(a, tuple) else self._B
         y = self._linear_slabs(blk.name, a, blk.w, B)
         H = y.shape[2]
-        act = self.buf(blk.name + ".act", (B, H), blk.out_t)
+        act = self.abuf(blk.name + ".act", (B, H), blk.out_t)
         yhat = self.buf(blk.name + ".yhat", (B, H)) if save else None
         rstd = self.buf(blk.name + ".rstd", (B,)) if save else None
         p = self.cfg["dr_rate"]
@@ -546,7 +581,7 @@ class StepEngine:
         H = self.p[blk.w].shape[0]
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if p > 0 else None
-        dh = self.buf(blk.name + ".dh", (B, H), blk.gt)
+        dh = self.abuf(blk.name + ".dh", (B, H), blk.gt)
         planes = self._tail_planes(blk.name + ".dh.pl", dh)
         if blk.norm:
             self._bn_bwd(blk, dact, mask, p if mask is not None else 0.0, dh, planes, extra, extra_scale)

@@ -24,3 +24,15 @@ for a, b in zip(cuts, cuts[1:] + [len(rows)]):
     g, n = max(gaps) if gaps else (0, "")
     slow = max(seg, key=lambda r: r[2] - r[1])
     print(f"step at {seg[0][1] / 1e6:12.3f} ms: span {span:9.1f} us, kernels {len(seg):4d}, busy {busy:9.1f} us, largest gap {g / 1e3:8.1f} us before {n[:50]}; longest {slow[0][:50]} {(slow[2] - slow[1]) / 1e3:.1f} us")
+
+# argv[3] (optional): index of a step whose launches are listed one by one (negative: from the end)
+if len(sys.argv) > 3:
+    k = int(sys.argv[3])
+    a = cuts[k]
+    b = cuts[k + 1] if k + 1 < len(cuts) and k != -1 else len(rows)
+    t0 = rows[a][1]
+    prev_end = t0
+    print(f"--- step {k}: {b - a} launches")
+    for n, s, e in rows[a:b]:
+        print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  gap {(s - prev_end) / 1e3:6.1f}  {n[:110]}")
+        prev_end = max(prev_end, e)
