@@ -84,6 +84,7 @@ _SIGS = {
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
                              vp, i64, vp]),
     "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),
+    "c2_defer_loss_sums": (i32, [i32]),
     "c2_scale4": (i32, [vp, f32, f32, f32, f32, vp, vp]),
     "c2_scale": (i32, [vp, vp, vp, i64, vp]),
     "c2_axpy": (i32, [vp, vp, vp, i64, vp]),

@@ -18,7 +18,29 @@ __global__ void finalize_sum_kernel(const float* __restrict__ partials, int n, f
     s = block_sum<256>(s, red);
     if (threadIdx.x == 0) *out += s;
 }
+// Deferred second stages (c2_defer_loss_sums): while on, the loss entry points of this thread do not launch their one-block
+// finalize kernel; the (partials, n, out) triples wait here until c2_combine_losses[_dev] sums them in the same launch that
+// forms the step's loss vector -- one launch instead of five or six (four finalizes, the zero-fill of the loss slots, the
+// combine) in a step whose small kernels each cost a ~4.5 us graph node.
+constexpr int kMaxPendingSums = 8;
+struct PendingSums {
+    const float* partials[kMaxPendingSums];
+    float* out[kMaxPendingSums];
+    int n[kMaxPendingSums];
+    int count;
+};
+static thread_local bool g_defer_sums = false;
+static thread_local PendingSums g_pending_sums = {};
+
 int launch_finalize_sum(const float* partials, int n, float* out, hipStream_t stream) {
+    if (g_defer_sums && g_pending_sums.count < kMaxPendingSums) {
+        PendingSums& p = g_pending_sums;
+        p.partials[p.count] = partials;
+        p.out[p.count] = out;
+        p.n[p.count] = n;
+        ++p.count;
+        return 0;
+    }
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, stream, partials, n, out);
     return 0;
 }
@@ -406,15 +428,20 @@ __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, bool two, float& v0
     v0 = bf2f(p[0]);
     v1 = two ? bf2f(p[1]) : 0.f;
 }
-template <typename TI, int CC>
+// DIRECT (short batches, B <= kBCG_DIRECT_B): one launch -- a block walks ALL rows of its 128 columns and writes alpha * sum
+// straight to db / dWc; at the reference's default batch of 128 the second stage was a launch with nothing to combine.
+constexpr int kBCG_DIRECT_B = 256;
+template <typename TI, int CC, bool DIRECT = false>
 __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ dh, int64_t lddh,
                                                         const int64_t* __restrict__ cond, int C, int c0, int64_t B, int H,
-                                                        float* __restrict__ ws /*[nchunk][1+C][H]*/) {
+                                                        float* __restrict__ ws /*[nchunk][1+C][H]*/,
+                                                        float* __restrict__ db = nullptr, float* __restrict__ dWc = nullptr,
+                                                        int64_t lddwc = 0, const float* __restrict__ alpha_dev = nullptr) {
     __shared__ float red[8][(1 + CC)][128];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 128 + 2 * cx;
     const int chunk = blockIdx.y;
-    const int64_t b0 = (int64_t)chunk * kBCG_RB, b1 = min(B, b0 + kBCG_RB);
+    const int64_t b0 = DIRECT ? 0 : (int64_t)chunk * kBCG_RB, b1 = DIRECT ? B : min(B, b0 + kBCG_RB);
     float a0[2] = {0.f, 0.f};
     float acc[CC > 0 ? CC : 1][2];
 #pragma unroll
@@ -452,7 +479,16 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += red[r][k][c];
-        out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = s;
+        if (DIRECT) {
+            s *= alpha_dev ? *alpha_dev : 1.f;
+            if (k == 0) {
+                if (db) db[gc] = s;
+            } else if (dWc) {
+                dWc[(int64_t)gc * lddwc + (c0 + k - 1)] = s;
+            }
+        } else {
+            out[(int64_t)(k == 0 ? 0 : c0 + k) * H + gc] = s;
+        }
     }
 }
 // 16-byte loads: block = 64 column groups (8 bf16 / 4 fp32 columns each) x 4 row groups; a thread walks every 4th row of
@@ -768,6 +804,39 @@ __global__ void combine_losses_dev_kernel(const float* __restrict__ l, const flo
         }
     }
 }
+// The pending second stages and the loss vector in one launch (256 threads).  Every sum is formed exactly as
+// finalize_sum_kernel forms it (same strides, same reduction tree): bit-identical to the separate launches.  The four loss
+// slots l[0..3] are taken as ZERO on entry (what they held is ignored) and receive the sums addressed to them; a sum
+// addressed elsewhere is added to its target.  w_dev NULL: the weights by value.
+__global__ __launch_bounds__(256) void finalize_combine_kernel(PendingSums p, float* __restrict__ l,
+                                                               const float* __restrict__ w_dev, float w0, float w1, float w2,
+                                                               float w3, float* __restrict__ out, double* __restrict__ accum) {
+    __shared__ float red[32];
+    float slot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.count; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < p.n[k]; i += 256) s += p.partials[k][i];
+        s = block_sum<256>(s, red);
+        const ptrdiff_t d = p.out[k] - l;
+        if (d >= 0 && d < 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (d == j) slot[j] += s;
+        } else if (threadIdx.x == 0) {
+            *p.out[k] += s;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (w_dev) { w0 = w_dev[0]; w1 = w_dev[1]; w2 = w_dev[2]; w3 = w_dev[3]; }
+        const float a = slot[0], b = slot[1], c = slot[2], d = slot[3];
+        const float t = ((w0 * a + w1 * b) + w2 * c) + w3 * d, u = (a + b) + c;
+        l[0] = a; l[1] = b; l[2] = c; l[3] = d;
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = t; out[5] = u;
+        if (accum) {
+            accum[0] += a; accum[1] += b; accum[2] += c; accum[3] += d; accum[4] += t; accum[5] += u;
+        }
+    }
+}
 __global__ void scale4_dev_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out) {
     if (threadIdx.x < 4) out[threadIdx.x] = w[threadIdx.x] * (g ? g[0] : 1.f);
 }
@@ -954,6 +1023,27 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
     if (H == 0) return 0;
     if (!dWc) C = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (B <= kBCG_DIRECT_B) {  // one launch, no second stage
+        dim3 g1((unsigned)((H + 127) / 128));
+#define BCD_L(TI, CC, c0)                                                                                              \
+    hipLaunchKernelGGL((bias_cond_stage1<TI, CC, true>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, \
+                       ws, db, dWc, lddwc, alpha_dev)
+        for (int c0 = 0; c0 == 0 || c0 < C; c0 += kBCG_MAXC) {
+            const int left = C - c0;
+            if (dh_dtype == C2_F32) {
+                if (left <= 0) BCD_L(float, 0, c0);
+                else if (left <= 4) BCD_L(float, 4, c0);
+                else BCD_L(float, 8, c0);
+            } else {
+                if (left <= 0) BCD_L(bf16_t, 0, c0);
+                else if (left <= 4) BCD_L(bf16_t, 4, c0);
+                else BCD_L(bf16_t, 8, c0);
+            }
+        }
+#undef BCD_L
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
     const int W = dh_dtype == C2_F32 ? 4 : 8;
     const bool vecp = H % W == 0 && lddh % W == 0 && aligned16(dh) && H >= 64 * W;
     // rows per chunk: 32 for the narrow matrices (more workgroups than 128-row chunks give), 128 otherwise / scalar path
@@ -1089,9 +1179,30 @@ extern "C" int c2_axpy(const float* x, const float* a_dev, float* y, int64_t n, 
     return 0;
 }
 
+extern "C" int c2_defer_loss_sums(int on) {
+    const int was = g_defer_sums ? 1 : 0;
+    if (on && !g_defer_sums) g_pending_sums.count = 0;  // nothing left over from a forward that never reached its combine
+    g_defer_sums = on != 0;
+    return was;
+}
+
+// the pending second stages, if any, in the launch that forms the loss vector
+static bool flush_pending_sums(const float* losses4, const float* w_dev, float w0, float w1, float w2, float w3, float* out6,
+                               double* accum6, hipStream_t st) {
+    if (g_pending_sums.count == 0) return false;
+    hipLaunchKernelGGL(finalize_combine_kernel, dim3(1), dim3(256), 0, st, g_pending_sums, const_cast<float*>(losses4), w_dev,
+                       w0, w1, w2, w3, out6, accum6);
+    g_pending_sums.count = 0;
+    return true;
+}
+
 extern "C" int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float w3, float* out6,
                                  void* stream) {
     C2_CHECK(losses4 && out6, "null pointer");
+    if (flush_pending_sums(losses4, nullptr, w0, w1, w2, w3, out6, nullptr, (hipStream_t)stream)) {
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(combine_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses4, w0, w1, w2, w3, out6);
     C2_LAUNCH_CHECK();
     return 0;
@@ -1107,6 +1218,10 @@ extern "C" int c2_scale4(const float* g_dev, float w0, float w1, float w2, float
 extern "C" int c2_combine_losses_dev(const float* losses4, const float* w_dev, float* out6, double* accum6,
                                      void* stream) {
     C2_CHECK(losses4 && w_dev && out6, "null pointer");
+    if (flush_pending_sums(losses4, w_dev, 0.f, 0.f, 0.f, 0.f, out6, accum6, (hipStream_t)stream)) {
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(combine_losses_dev_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses4, w_dev, out6, accum6);
     C2_LAUNCH_CHECK();
     return 0;

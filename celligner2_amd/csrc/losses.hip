@@ -895,6 +895,50 @@ __global__ __launch_bounds__(256) void nb_colsum_kernel(const TD* __restrict__ d
     for (int64_t b = b0; b < b1; ++b) s += ld_as_f32(d + b * ld + g);
     part2[((int64_t)sl * 4 + 3) * G + g] = s;
 }
+// Few workgroup partials (a batch of at most kDthDirect rows: the reference's default 128): ONE launch instead of stage 1 +
+// column sums + stage 2.  A block is 64 genes x 4 groups; group r sums every 4th workgroup partial (and every 4th row of
+// dlogits for the bias gradient), the four are combined through LDS and the results written in their final layout.
+constexpr int kDthDirect = 256;
+template <typename TD>
+__global__ __launch_bounds__(256) void nb_dtheta_direct(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
+                                                        int ngroups, int64_t G, int C, float* __restrict__ dtheta,
+                                                        const TD* __restrict__ d /*dlogits or NULL*/, int64_t ld, int64_t B,
+                                                        float* __restrict__ db /*or NULL*/) {
+    __shared__ float red[4][4][64];
+    __shared__ int flag[kDthDirect * 3];  // the partials' valid flags: read once, so that the loads below are independent
+    const int lx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int64_t g = blockIdx.x * 64ll + lx;
+    for (int i = threadIdx.x; i < ngroups * 3; i += 256) flag[i] = part_flag[i];
+    __syncthreads();
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < G) {
+#pragma unroll 4
+        for (int grp = ry; grp < ngroups; grp += 4) {
+            float v[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) v[p] = flag[grp * 3 + p] ? part_dt[((int64_t)grp * 3 + p) * G + g] : 0.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) s[p] += v[p];
+        }
+        if (db && d) {
+#pragma unroll 8
+            for (int64_t b = ry; b < B; b += 4) s[3] += ld_as_f32(d + b * ld + g);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) red[ry][p][lx] = s[p];
+    __syncthreads();
+    if (ry != 0 || g >= G) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s[p] = (red[0][p][lx] + red[1][p][lx]) + (red[2][p][lx] + red[3][p][lx]);
+    for (int j = 0; j < C; ++j) {
+        float v = 0.f;
+        if (j == 0) v = s[0] + s[2];
+        if (j == 1) v = s[1] + s[2];
+        dtheta[g * C + j] = v;
+    }
+    if (db) db[g] = s[3];
+}
 __global__ __launch_bounds__(256) void nb_dtheta_stage2(const float* __restrict__ part2, int64_t G, int C,
                                                         float* __restrict__ dtheta, float* __restrict__ db /*or NULL*/) {
     const int64_t g = blockIdx.x * 256ll + threadIdx.x;
@@ -1500,6 +1544,18 @@ static int recon_nb_run(const float* logits, int64_t ldl, const float* x, int64_
     if (db_in_kernel) a.part_db = part_db;
     int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
     C2_CHECK(rc == 0, "unsupported G");
+    if (ngroups <= kDthDirect && B <= kDthDirect && !db_in_kernel) {
+        const dim3 grid((unsigned)((G + 63) / 64));
+        if (dl_dtype == C2_BF16)
+            hipLaunchKernelGGL(nb_dtheta_direct<bf16_t>, grid, dim3(256), 0, st, part_dt, part_flag, ngroups, G, C, dtheta,
+                               (const bf16_t*)dlogits, lddl, B, dbias);
+        else
+            hipLaunchKernelGGL(nb_dtheta_direct<float>, grid, dim3(256), 0, st, part_dt, part_flag, ngroups, G, C, dtheta,
+                               (const float*)dlogits, lddl, B, dbias);
+        launch_finalize_sum(part_loss, ngroups, loss_out, st);
+        C2_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
                        ngroups, G, part2, db_in_kernel ? part_db : (const float*)nullptr);
     if (dbias && !db_in_kernel) {

@@ -634,7 +634,19 @@ class StepEngine:
                    dh, planes=planes)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch, eps, masks, train=True, save=True, classes_given=True):
+    def forward(self, batch, eps, masks, train=True, save=True, classes_given=True, defer_sums=False):
+        """defer_sums: the caller hands the returned loss slots to ops.combine_losses[_dev] next, which then also sums the
+        loss kernels' partials (c2_defer_loss_sums): the slots are only valid after that call."""
+        defer = bool(defer_sums) and not self.exchange  # (ranks all-reduce the four sums before they are combined)
+        if not defer:
+            return self._forward(batch, eps, masks, train, save, classes_given, False)
+        ops.defer_loss_sums(True)
+        try:
+            return self._forward(batch, eps, masks, train, save, classes_given, True)
+        finally:
+            ops.defer_loss_sums(False)
+
+    def _forward(self, batch, eps, masks, train, save, classes_given, deferred):
         """batch: dict of device tensors x [B,G] f32, batch [B,C] i64, sizefactor [B] f32, goodloc [B,G] bool,
         classes [B,P] i64 or None.  Returns a fp32 [4] tensor (recon, kl, mmd, class_ce); leaves everything the
         backward needs in the workspace."""
@@ -652,7 +664,8 @@ class StepEngine:
         self._B, self._cond, self._masks, self._eps = B, cond, masks, eps
         self._aplanes = {}
         losses = self._ws["losses"] = self.buf("losses4", (4,))
-        losses.zero_()
+        if not deferred:  # (the combine launch that sums the deferred partials writes all four slots)
+            losses.zero_()
         # status words are STICKY: the kernels only ever write them on an error, and check_status() alone clears them,
         # so a bad batch anywhere in an epoch is still reported at the epoch's end
         status = self._ws.get("status")
@@ -697,7 +710,11 @@ class StepEngine:
         L = cfg["latent"]
         mu, lv = self._heads_fwd(a, B, L)
         z32 = self.buf("z32", (B, L))
+        # one partial-sum workspace per loss term: with deferred second stages (c2_defer_loss_sums) each term's partials
+        # must stay untouched until the combine launch sums them
         red_ws = self.buf("red.ws", (int(ops.lib.c2_reduce_ws()),))
+        red_ws_mse = self.buf("red.ws.mse", (int(ops.lib.c2_reduce_ws()),)) if cfg["recon_loss"] == "mse" else None
+        red_ws_cls = self.buf("red.ws.cls", (int(ops.lib.c2_reduce_ws()),))
         zdt = self.dec[0].gt
         zt = self.buf("zt", (B, L), zdt) if zdt != F32 else z32
         ops.reparam_kl_fwd(mu, lv, eps, inv_B, cfg["use_own_kl"], z32, zt if zdt != F32 else None,
@@ -732,7 +749,7 @@ class StepEngine:
         elif cfg["recon_loss"] == "mse":
             if x is None:
                 raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")
-            ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws)
+            ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws_mse)
         else:  # zinb: second gene-width head for the dropout logits (modules.py:471-477, celligner2.py:286-296)
             pi = self.buf("pi", (B, G))
             self._fwd(d, self.head2 + ".weight", pi, bias=self.p[self.head2 + ".bias"].detach())
@@ -761,7 +778,7 @@ class StepEngine:
                 u = self.buf("u", (B, P))
                 self._fwd(c, "classifier.classifier.0.weight", u, bias=self.p["classifier.classifier.0.bias"].detach())
                 du = self.buf("du", (B, P), self.gemm_dtype("classifier.classifier.0.weight"))
-                ops.classifier_loss(u, classes, cfg["betaclass"], losses[3:4], du, red_ws)
+                ops.classifier_loss(u, classes, cfg["betaclass"], losses[3:4], du, red_ws_cls)
         # ---- MMD over the (global) batch
         self._dfeat = None
         if cfg["use_mmd"]:

@@ -199,7 +199,7 @@ class _StepTotalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, eps, masks, weights, *params):
         eng = model.__dict__["_eng"]  # validated by Celligner2.forward just before
-        losses = eng.forward(batch, eps, masks, train=model.training, save=True)
+        losses = eng.forward(batch, eps, masks, train=model.training, save=True, defer_sums=True)
         out6 = torch.empty(6, dtype=torch.float32, device=eng.dev)  # fresh per step: the logs keep views of it
         if torch.is_tensor(weights):  # device-resident weights (a step that is replayed as a HIP graph)
             ops.combine_losses_dev(losses, weights, out6, model.__dict__.get("_loss_sums"))
@@ -530,7 +530,7 @@ class Celligner2(nn.Module):
         eng = self._engine()
         if weights is not None:
             out6 = torch.empty(6, dtype=torch.float32, device=dev)
-            losses = eng.forward(bt, eps, masks, train=self.training, save=False)
+            losses = eng.forward(bt, eps, masks, train=self.training, save=False, defer_sums=True)
             if torch.is_tensor(weights):
                 ops.combine_losses_dev(losses, weights, out6)
             else:

@@ -572,6 +572,11 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
                              stream()))
 
 
+def defer_loss_sums(on):
+    """While on, the loss entry points leave their second-stage sums to the next combine_losses[_dev] (one launch)."""
+    return bool(lib.c2_defer_loss_sums(1 if on else 0))
+
+
 def combine_losses(losses4, weights, out6):
     """out6 = (recon, kl, mmd, ce, weighted total, recon + kl + mmd)."""
     L.require_gpu(losses4, out6)

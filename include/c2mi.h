@@ -329,6 +329,16 @@ int c2_dropout_masks(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint6
  * :69 `unweighted_loss`): out6 = (recon, kl, mmd, ce, w0*recon + w1*kl + w2*mmd + w3*ce, recon + kl + mmd). */
 int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float w3, float* out6, void* stream);
 
+/* c2_defer_loss_sums(1): from now on the loss entry points called by THIS thread (c2_recon_*_fwd_bwd, c2_reparam_kl_fwd,
+ * c2_classifier_loss_fwd_bwd, c2_mmd_fwd_bwd) leave their partial sums in their workspaces instead of launching the
+ * one-block kernel that adds them to *loss_out, and the next c2_combine_losses / c2_combine_losses_dev of this thread sums
+ * them in its own launch: the four slots of losses4 are then taken as zero on entry and receive the sums addressed to
+ * them (no zero-fill needed), a sum addressed elsewhere is added to its target; sums are formed exactly as the separate
+ * launches form them (bit-identical).  At most 8 sums wait; further ones are launched at once.  c2_defer_loss_sums(0)
+ * ends the mode (sums already waiting stay until the next combine).  Returns the previous setting.  No counterpart in
+ * the reference (semisupervised.py:63-69 sums with torch ops): it removes five ~4.5 us graph nodes from a replayed step. */
+int c2_defer_loss_sums(int on);
+
 /* Its backward seed: out4[i] = w_i * g (g = *g_dev, or 1 when g_dev is NULL) -- the upstream gradients of the four
  * losses when the weighted total receives gradient g. */
 int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float* out4, void* stream);

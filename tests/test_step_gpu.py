@@ -383,15 +383,17 @@ def test_one_workspace_guards_stale_forward_accumulation_weight_and_sticky_statu
     # accumulate a second backward on top of the handed-over views
     r, k, m, c = model(**mk())
     (r + 1e-3 * k + m + c).backward()
+    # (`single` came from a backward behind a no-grad forward, which leaves the output layer's bias gradient to the
+    # column-sum kernel instead of the loss kernel's own sums: two summation orders, equal to fp32 reassociation)
     for n, p in model.named_parameters():
         if n in single:
-            assert torch.allclose(p.grad, 2 * single[n], rtol=1e-6, atol=1e-12), n
+            assert torch.allclose(p.grad, 2 * single[n], rtol=1e-5, atol=2e-6 * float(single[n].abs().max())), n
     model.zero_grad(set_to_none=False)
     r, k, m, c = model(**mk())
     (r + 1e-3 * k + m + c).backward()
     for n, p in model.named_parameters():
         if n in single:
-            assert torch.allclose(p.grad, single[n], rtol=1e-6, atol=1e-12), n
+            assert torch.allclose(p.grad, single[n], rtol=1e-5, atol=1e-6 * float(single[n].abs().max())), n
     with pytest.raises(NotImplementedError):
         model(weight=torch.ones(3, device=DEV), **mk())
     # sticky status
