@@ -42,6 +42,8 @@ _SIGS = {
     "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_fwd_rows": (i32, [vp, i64, i64, vp, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad_rows": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad_rows_at": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad_bt": (i32, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_gemm_tile": (i32, [i32, i64, i64, i64]),
     "c2_split_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs_2d": (i32, [vp, i32, i64, i64, i64, i64, vp, i64, vp]),
@@ -81,6 +83,7 @@ _SIGS = {
     "c2_scale4_dev": (i32, [vp, vp, vp, vp]),
     "c2_dropout_masks_dev": (i32, [vp, i64, f32, C.c_uint64, vp, C.c_uint64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "c2_transpose_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
                              vp, i64, vp]),
     "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),

@@ -1257,6 +1257,36 @@ extern "C" int c2_scale(const float* x, const float* a_dev, float* y, int64_t n,
     return 0;
 }
 
+// dst[c][r] = src[r][c] for 2-byte elements: 64 x 64 tiles through LDS (padded rows: no bank conflicts on the column read)
+__global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restrict__ src, int64_t lds_, int64_t rows,
+                                                          int64_t cols, bf16_t* __restrict__ dst, int64_t ldd) {
+    __shared__ bf16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = blockIdx.y * 64ll, c0 = blockIdx.x * 64ll;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < rows && c < cols) ? src[r * lds_ + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * ldd + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+extern "C" int c2_transpose_bf16(const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
+                                 void* stream) {
+    C2_CHECK(src && dst && ld_src >= cols && ld_dst >= rows && rows >= 0 && cols >= 0, "bad arguments");
+    if (rows == 0 || cols == 0) return 0;
+    C2_CHECK((rows + 63) / 64 < 65536, "too many rows");
+    hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     C2_CHECK(src && dst && n >= 0, "bad arguments");
     if (n == 0) return 0;

@@ -7,7 +7,8 @@ namespace c2 {
 
 // C[M,N] = alpha * sum_r Aop[i][r] * Bop[j][r] (+ bias[j]).  Each operand is "RC" (reduction index contiguous:
 // element (x,r) at p[x*ld + r]) or "XC" (output index contiguous: element (x,r) at p[r*ld + x]).
-// layout 0 = (RC,RC) forward, 1 = (RC,XC) dgrad, 2 = (XC,XC) wgrad.
+// layout 0 = (RC,RC) forward, 1 = (RC,XC) dgrad, 2 = (XC,XC) wgrad, 3 = (XC,RC) wgrad with the second operand transposed
+// (256x256 LDS-DMA kernel only); row-indexed launches also take 4 = (RC, XC with indexed reduction rows).
 struct GemmArgs {
     const void* A;
     const void* B;

@@ -322,6 +322,7 @@ static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
     const int wt = (wide_enabled() || dtype == C2_BF16X3P) ? wide_tile(dtype, a) : 0;
+    if (layout == 3 && (wt != 256 || dtype != C2_BF16)) return 3;  // (XC, RC) exists on the 256x256 kernel only
     if (wt) return launch_gemm_wide(layout, wt, a, nslab, stream);
     if (dtype == C2_BF16X3P) return 3;  // planes only run on the LDS-DMA kernels
     if (dtype == C2_BF16) return gemm_layout<bf16_t>(layout, a, nslab, stream);
@@ -471,6 +472,42 @@ extern "C" int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_
     a.r_per_split = (int)((per + 63) / 64 * 64);
     C2_CHECK(launch_gemm_wide_rows(2, a, nslab, (hipStream_t)stream) == 0,
              "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): gather the rows instead");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const void* A_full, int64_t lda, int64_t a_rows,
+                                       const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw,
+                                       int nslab, int64_t slab_stride, const float* alpha_dev, void* stream) {
+    C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
+    C2_CHECK(dYt && A_full && row_index && dW, "null pointer");
+    C2_CHECK(lddyt >= M && lda >= K && lddw >= K, "leading dimension too small");
+    C2_CHECK(a_rows >= 1 && a_rows * lda < (1ll << 31), "resident matrix too large for 32-bit element offsets");
+    C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
+    if (N == 0 || K == 0) return 0;
+    // C[n][k] = sum_m dYt[n][m] A[rows[m]][k]: A-op = dYt (RC over m), B-op = A_full (XC over k, reduction rows indexed)
+    GemmArgs a{dYt, A_full, dW, nullptr, alpha_dev, lddyt, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr,
+               row_index};
+    int64_t per = (a.R + nslab - 1) / nslab;
+    a.r_per_split = (int)((per + 63) / 64 * 64);
+    C2_CHECK(launch_gemm_wide_rows(4, a, nslab, (hipStream_t)stream) == 0,
+             "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): use c2_linear_wgrad_rows");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, int64_t ldat, int64_t M, int64_t N,
+                                  int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
+                                  const float* alpha_dev, void* stream) {
+    C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
+    C2_CHECK(dY && At && dW, "null pointer");
+    C2_CHECK(lddy >= N && ldat >= M && lddw >= K, "leading dimension too small");
+    C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
+    if (N == 0 || K == 0) return 0;
+    // C[n][k] = sum_m dY[m][n] At[k][m]: A-op = dY (XC over n), B-op = At (RC over m)
+    GemmArgs a{dY, At, dW, nullptr, alpha_dev, lddy, ldat, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
+    C2_CHECK(gemm_dispatch(3, C2_BF16, a, nslab, (hipStream_t)stream) == 0,
+             "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): use c2_linear_wgrad");
     C2_LAUNCH_CHECK();
     return 0;
 }

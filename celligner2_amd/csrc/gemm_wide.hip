@@ -783,13 +783,22 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
         hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     else if (layout == 1)
         hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
-    else
+    else if (layout == 3) {  // (XC, RC): a weight gradient whose second operand was handed over transposed
+        if constexpr (NW == 8) {
+            static bool attr3 = false;
+            if (!attr3) {
+                (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                attr3 = true;
+            }
+            hipLaunchKernelGGL((gemm_wide_kernel<false, true, 8>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
+        }
+    } else
         hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
 }
 
 int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
     using namespace wide;
-    if (!a.rows || a.A_lo || (layout != 0 && layout != 2) || wide_tile(C2_BF16, a) != 256) return 3;
+    if (!a.rows || a.A_lo || (layout != 0 && layout != 2 && layout != 4) || wide_tile(C2_BF16, a) != 256) return 3;
     constexpr int NW = 8, BX = 256;
     constexpr int LDS = 5 * BX * BK * 2;
     const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;
@@ -798,10 +807,13 @@ int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t 
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, true, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, false, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     if (layout == 0)
         hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW, 1>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
+    else if (layout == 4)  // (RC, XC with indexed reduction rows): the weight gradient with dY handed over transposed
+        hipLaunchKernelGGL((gemm_wide_kernel<true, false, NW, 2>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     else
         hipLaunchKernelGGL((gemm_wide_kernel<false, false, NW, 2>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);
     return 0;

@@ -34,6 +34,28 @@ class _Block:
         self.out_t = F32  # dtype of its activation = operand dtype of the consumer GEMM
 
 
+class _T:
+    """A [B, H] operand held as its transposed copy t = [H, B] (StepEngine._narrow_t)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return (self.t.shape[1], self.t.shape[0])
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    def cols(self, sl):
+        return _T(self.t[sl])
+
+
+def _cols(x, sl):
+    return x.cols(sl) if isinstance(x, _T) else x[:, sl]
+
+
 class StepEngine:
     def __init__(self, cfg, params, precision="fp32", bn_modules=None):
         """cfg: dict of model options (see model.Celligner2._cfg); params: {name: Parameter};
@@ -454,6 +476,7 @@ class StepEngine:
             g = self.gbuf(name)
         N, K = g.shape
         if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): gene-width by construction
+            dy = self._narrow_t(dy, "dyt", N, K)  # (the narrow operand transposed: see _narrow_t)
             if not self._wgrad_two_part(dy, a, g, alpha):
                 ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
                 if ns == 1:
@@ -464,8 +487,19 @@ class StepEngine:
                     ops.sum_slabs(slabs, g)
             return
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
-        if not pl and self._wgrad_two_part(dy, a, g, alpha):
-            return
+        if not pl:
+            at = self._narrow_t(a, "at", N, K)
+            if self._wgrad_two_part(dy, at, g, alpha):
+                return
+            if isinstance(at, _T):
+                ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
+                if ns == 1:
+                    self._wg(dy, at, g, alpha=alpha)
+                else:
+                    slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
+                    self._wg(dy, at, slabs, nslab=ns, alpha=alpha)
+                    ops.sum_slabs(slabs, g)
+                return
         ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3, planes=pl)
         if ns == 1:
             ops.linear_wgrad(dy2, a2, g, alpha=alpha, x3=self.x3)
@@ -474,13 +508,30 @@ class StepEngine:
             ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
 
+    def _narrow_t(self, t, key, N, K):
+        """A gene-width bf16 weight gradient [N, K] reduced over the batch multiplies faster when its NARROW operand
+        ([B, H]: 8 MB at 4096 x 1024) is handed over transposed -- the cells contiguous, read row-wise, 16x16x32 MFMA -- than
+        with both operands through the transposing LDS read (c2_linear_wgrad_bt / _rows_at; same result bit for bit).
+        Returns the transposed copy wrapped in _T when the 256x256 kernel takes the shape, else `t` unchanged."""
+        B, H = t.shape
+        if not (t.dtype == torch.bfloat16 and B % 8 == 0 and B >= 1024 and H <= 2048 and max(N, K) >= self.WIDE
+                and ops.gemm_tile(t.dtype, N, K, B, self.x3) == 256):
+            return t
+        return _T(ops.transpose_bf16(t, self.buf(f"wgrad.{key}.{H}x{B}", (H, B), torch.bfloat16)))
+
     @staticmethod
     def _wg(dy, a, out, nslab=1, alpha=None, cols=None):
         """Weight-gradient launch for a plain activation matrix or a (resident matrix, row index) pair; cols: column
-        slice of the activation."""
+        slice of the activation.  A _T operand is the transposed copy _narrow_t made (dy for the row-indexed form, the
+        activation otherwise); slices of it are taken along its rows."""
         if isinstance(a, tuple):
             af = a[0] if cols is None else a[0][:, cols]
-            ops.linear_wgrad_rows(dy, af, a[1], out, nslab=nslab, alpha=alpha)
+            if isinstance(dy, _T):
+                ops.linear_wgrad_rows_at(dy.t, af, a[1], out, nslab=nslab, alpha=alpha)
+            else:
+                ops.linear_wgrad_rows(dy, af, a[1], out, nslab=nslab, alpha=alpha)
+        elif isinstance(a, _T):
+            ops.linear_wgrad_bt(dy, a.t if cols is None else a.t[cols], out, nslab=nslab, alpha=alpha)
         else:
             ops.linear_wgrad(dy, a if cols is None else a[:, cols], out, nslab=nslab, alpha=alpha)
 
@@ -503,9 +554,9 @@ class StepEngine:
         tiles2 = ((rest + 255) // 256) * per
         ns = max(1, min(16, 256 // tiles2, M // 256))
         if by_rows:
-            self._wg(dy[:, :cut], a, g[:cut], alpha=alpha)
+            self._wg(_cols(dy, slice(0, cut)), a, g[:cut], alpha=alpha)
             slabs = self.buf(f"wgrad.strip.{ns}x{rest}x{K}", (ns, rest, K))
-            self._wg(dy[:, cut:], a, slabs, nslab=ns, alpha=alpha)
+            self._wg(_cols(dy, slice(cut, None)), a, slabs, nslab=ns, alpha=alpha)
             ops.sum_slabs(slabs, g[cut:])
         else:
             self._wg(dy, a, g[:, :cut], alpha=alpha, cols=slice(0, cut))

@@ -153,6 +153,38 @@ def linear_wgrad_rows(dy, a_full, rows, dw, nslab=1, alpha=None):
     return dw
 
 
+def linear_wgrad_rows_at(dyt, a_full, rows, dw, nslab=1, alpha=None):
+    """linear_wgrad_rows with dy handed over transposed: dyt [N, M] bf16 (the cells contiguous)."""
+    L.require_gpu(dyt, a_full, rows, dw)
+    N, M = dyt.shape
+    _rows_arg(a_full, rows, (M + 63) // 64 * 64)
+    K = a_full.shape[1]
+    assert dyt.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    d2 = dw if dw.dim() == 2 else dw[0]
+    assert tuple(d2.shape) == (N, K) and ((dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1)
+    ss = dw.stride(0) if dw.dim() == 3 else 0
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_wgrad_rows_at(ptr(dyt), _row_major(dyt, "dyt"), ptr(a_full), a_full.stride(0),
+                                          a_full.shape[0], ptr(rows), M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
+                                          ptr(alpha), stream()))
+    return dw
+
+
+def linear_wgrad_bt(dy, at, dw, nslab=1, alpha=None):
+    """dw[s] = alpha * dy.T @ at.T with the second operand handed over transposed: dy [M, N], at [K, M], both bf16."""
+    L.require_gpu(dy, at, dw)
+    M, N = dy.shape
+    K, M2 = at.shape
+    assert M2 == M and dy.dtype == torch.bfloat16 and at.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    d2 = dw if dw.dim() == 2 else dw[0]
+    assert tuple(d2.shape) == (N, K) and ((dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1)
+    ss = dw.stride(0) if dw.dim() == 3 else 0
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_wgrad_bt(ptr(dy), _row_major(dy, "dy"), ptr(at), _row_major(at, "at"), M, N, K, ptr(dw),
+                                     _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
+    return dw
+
+
 def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     """da[s] = alpha * dy @ w.   dy [M,N], w [N,K], da [M,K] or [nslab,M,K]."""
     L.require_gpu(dy, w, da)
@@ -545,6 +577,15 @@ def adam_step_dev(entries, hyper):
     arr, n = _adam_table(entries)
     L.require_gpu(hyper)
     check(lib.c2_adam_step_dev(arr, n, ptr(hyper), stream()))
+
+
+def transpose_bf16(src, dst):
+    """dst [C, R] = src [R, C] transposed (bf16, unit inner strides)."""
+    L.require_gpu(src, dst)
+    R, Cc = src.shape
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and tuple(dst.shape) == (Cc, R)
+    check(lib.c2_transpose_bf16(ptr(src), _row_major(src, "src"), R, Cc, ptr(dst), _row_major(dst, "dst"), stream()))
+    return dst
 
 
 def cast_bf16(src, dst):

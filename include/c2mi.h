@@ -85,6 +85,22 @@ int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64
                          const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
                          int64_t slab_stride, const float* alpha_dev, void* stream);
 
+/* The gene-width weight gradient (nn.Linear backward, modules.py:281-290, 467-482) with ONE operand handed over
+ * TRANSPOSED, so that its reduction index (the cells of the batch) is contiguous and the 256x256 kernel reads it row-wise
+ * and multiplies on v_mfma_f32_16x16x32_bf16 -- the layout of the forward / input-gradient launches, measured faster than
+ * the weight gradient whose two operands both come through the transposing LDS read.  The transposed operand is the narrow
+ * one ([B, H]: 8 MB at 4096 x 1024), so making the copy is cheap; the gene-width operand stays as it is.
+ *   c2_linear_wgrad_bt:       dW[n][k] = alpha * sum_m dY[m][n] At[k][m]                  At: [K, M] bf16
+ *   c2_linear_wgrad_rows_at:  dW[n][k] = alpha * sum_m dYt[n][m] A_full[row_index[m]][k]  dYt: [N, M] bf16
+ * bf16, shapes the 256x256 kernel takes only (c2_gemm_tile(C2_BF16, N, K, M) == 256, 16-byte aligned rows); otherwise an
+ * error -- use c2_linear_wgrad / c2_linear_wgrad_rows.  Results equal those entry points' up to fp32 summation order
+ * inside the MFMA (same products, same K-tile order). */
+int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, int64_t ldat, int64_t M, int64_t N, int64_t K,
+                       float* dW, int64_t lddw, int nslab, int64_t slab_stride, const float* alpha_dev, void* stream);
+int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const void* A_full, int64_t lda, int64_t a_rows,
+                            const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
+                            int64_t slab_stride, const float* alpha_dev, void* stream);
+
 /* Block-tile edge (128 or 256) the three GEMM entry points above use for operand dtype `dtype` and an
  * [M,N] output reduced over R: callers size `nslab` from it so that a launch fills the 256 CUs.
  * 0 = this dtype cannot take the shape (C2_BF16X3P only).
@@ -264,6 +280,9 @@ typedef struct {
 size_t c2_adam_hyper_bytes(void);
 int c2_adam_prepare(c2_adam_state* state_dev, void* hyper_dev, void* stream);
 int c2_adam_step_dev(const c2_adam_tensor* desc_host, int n_tensors, const void* hyper_dev, void* stream);
+
+/* dst[c][r] = src[r][c], bf16 (or any 2-byte type): the narrow operand of c2_linear_wgrad_bt / c2_linear_wgrad_rows_at. */
+int c2_transpose_bf16(const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);
 
 /* fp32 -> bf16 copy (initial weight shadows), n elements. */
 int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -871,3 +871,34 @@ def test_mmd_at_the_eight_gpu_shape():
         out.append((loss.item(), df))
     assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[1][0]), (out[0][0], out[1][0])
     assert rel(out[0][1], out[1][1].cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,nslab", [(4096, 1024, 19000, 1), (2048, 1280, 4096, 2), (1032, 820, 4104, 1)])
+def test_weight_gradient_with_a_transposed_operand(M, N, K, nslab):
+    """c2_linear_wgrad_bt / c2_linear_wgrad_rows_at (one operand handed over transposed, read row-wise, 16x16x32 MFMA)
+    against c2_linear_wgrad / c2_linear_wgrad_rows: the same products in the same order, bit for bit; and the transpose
+    kernel itself.  Ragged edges, split reductions, a width that is not a multiple of 8 (padded rows)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    ldn = (N + 7) // 8 * 8
+    dy = torch.randn(M, ldn, generator=g).to(DEV).to(torch.bfloat16)[:, :N]
+    a = torch.randn(M + 5, K, generator=g).to(DEV).to(torch.bfloat16)
+    rows = torch.randint(0, M + 5, ((M + 63) // 64 * 64,), generator=g).to(torch.int32).to(DEV)
+    dyt = ops.transpose_bf16(dy, torch.empty(N, M, device=DEV, dtype=torch.bfloat16))
+    assert torch.equal(dyt, dy.t())
+    alpha = torch.tensor([0.25], device=DEV)
+    shape = (nslab, N, K) if nslab > 1 else (N, K)
+    d0, d1 = torch.empty(shape, device=DEV), torch.empty(shape, device=DEV)
+    ops.linear_wgrad_rows(dy, a, rows, d0, nslab=nslab, alpha=alpha)
+    ops.linear_wgrad_rows_at(dyt, a, rows, d1, nslab=nslab, alpha=alpha)
+    assert torch.equal(d0, d1)
+    # the other side transposed: dW[K2, N] = dl^T @ dy with dy as the narrow operand
+    K2 = 4608
+    dl = torch.randn(M, K2, generator=g).to(DEV).to(torch.bfloat16)
+    shape = (nslab, K2, N) if nslab > 1 else (K2, N)
+    e0, e1 = torch.empty(shape, device=DEV), torch.empty(shape, device=DEV)
+    ops.linear_wgrad(dl, dy, e0, nslab=nslab, alpha=alpha)
+    ops.linear_wgrad_bt(dl, dyt, e1, nslab=nslab, alpha=alpha)
+    assert torch.equal(e0, e1)
+    with pytest.raises(ops.L.C2Error):  # a shape the 256x256 kernel does not take
+        ops.linear_wgrad_bt(dl[:64, :128], dyt[:128, :64].contiguous(), torch.empty(128, 128, device=DEV))

@@ -31,6 +31,22 @@ def main():
         "head_wgrad TN [19000,1024] R=4096": lambda y=torch.empty(G, H, device=dev): ops.linear_wgrad(dl, d1, y),
         "enc0_wgrad TN [1024,19000] R=4096": lambda y=torch.empty(H, G, device=dev): ops.linear_wgrad(dh0, x, y),
     }
+    # the weight gradients with one (narrow) operand transposed: (XC, RC) and (RC, XC rows) on v_mfma_16x16x32
+    d1t, dh0t = d1.t().contiguous(), dh0.t().contiguous()
+    rows = torch.arange(B, device=dev, dtype=torch.int32)
+    y_ref = torch.empty(G, H, device=dev)
+    ops.linear_wgrad(dl, d1, y_ref)
+    y_bt = torch.empty(G, H, device=dev)
+    ops.linear_wgrad_bt(dl, d1t, y_bt)
+    print("head_wgrad_bt vs wgrad: max rel diff", float((y_bt - y_ref).abs().max() / y_ref.abs().max()))
+    y_ref2 = torch.empty(H, G, device=dev)
+    ops.linear_wgrad_rows(dh0, x, rows, y_ref2)
+    y_at = torch.empty(H, G, device=dev)
+    ops.linear_wgrad_rows_at(dh0t, x, rows, y_at)
+    print("enc0_wgrad_rows_at vs wgrad_rows: max rel diff", float((y_at - y_ref2).abs().max() / y_ref2.abs().max()))
+    cases["head_wgrad_bt (XC,RC) [19000,1024] R=4096"] = lambda y=y_bt: ops.linear_wgrad_bt(dl, d1t, y)
+    cases["enc0_wgrad_rows TN rows [1024,19000] R=4096"] = lambda y=y_ref2: ops.linear_wgrad_rows(dh0, x, rows, y)
+    cases["enc0_wgrad_rows_at (RC,XC rows) [1024,19000]"] = lambda y=y_at: ops.linear_wgrad_rows_at(dh0t, x, rows, y)
     for name, fn in cases.items():
         if which != "all" and which not in name: continue
         us = bench(fn, reps)
