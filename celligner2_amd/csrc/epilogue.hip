@@ -1257,12 +1257,36 @@ extern "C" int c2_scale(const float* x, const float* a_dev, float* y, int64_t n,
     return 0;
 }
 
-// dst[c][r] = src[r][c] for 2-byte elements: 64 x 64 tiles through LDS (padded rows: no bank conflicts on the column read)
+// dst[c][r] = src[r][c] for 2-byte elements: 64 x 64 tiles through LDS.  VEC (16-byte aligned rows on both sides, whole
+// tiles): a thread loads two 16-byte chunks of a source row and stores two 16-byte chunks of a destination row (eight lanes
+// cover 128 contiguous bytes); the tile's rows are 33 words apart, so the eight row chunks x four column words a wave reads
+// per step fall on distinct banks.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restrict__ src, int64_t lds_, int64_t rows,
                                                           int64_t cols, bf16_t* __restrict__ dst, int64_t ldd) {
     __shared__ bf16_t tile[64][66];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t r0 = blockIdx.y * 64ll, c0 = blockIdx.x * 64ll;
+    if (VEC) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = threadIdx.x + 256 * h, r = q >> 3, ch = q & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (r0 + r) * lds_ + c0 + 8 * ch);
+            unsigned* t = reinterpret_cast<unsigned*>(&tile[r][8 * ch]);
+            t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = threadIdx.x + 256 * h, c = q >> 3, rc = q & 7;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = (unsigned)tile[8 * rc + 2 * e][c] | ((unsigned)tile[8 * rc + 2 * e + 1][c] << 16);
+            *reinterpret_cast<u32x4*>(dst + (c0 + c) * ldd + r0 + 8 * rc) = o;
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
@@ -1281,8 +1305,14 @@ extern "C" int c2_transpose_bf16(const void* src, int64_t ld_src, int64_t rows, 
     C2_CHECK(src && dst && ld_src >= cols && ld_dst >= rows && rows >= 0 && cols >= 0, "bad arguments");
     if (rows == 0 || cols == 0) return 0;
     C2_CHECK((rows + 63) / 64 < 65536, "too many rows");
-    hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst);
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    const bool vec = rows % 64 == 0 && cols % 64 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && aligned16(src) && aligned16(dst);
+    if (vec)
+        hipLaunchKernelGGL(transpose16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, rows,
+                           cols, (bf16_t*)dst, ld_dst);
+    else
+        hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
+                           rows, cols, (bf16_t*)dst, ld_dst);
     C2_LAUNCH_CHECK();
     return 0;
 }
