@@ -158,6 +158,19 @@ def main():
     args = ap.parse_args()
 
     backend = os.environ.get("C2_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" in os.environ or args.gpus == 1:
+        # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to stdout when
+        # the first communicator comes up): from here on file descriptor 1 is the error stream, and the result line goes
+        # to the saved original.  (The self-launching parent below keeps its stdout: its children inherit it.)
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
+    else:
+        result_fd = 1
+
+    def emit(obj):
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             sys.exit(_self_launch(args.gpus))
@@ -335,8 +348,8 @@ def main():
     # too short for a power-managed chip to settle; `value` stays the K-step figure the contract asks for.
     if args.profile_pass:
         if rank == 0:
-            print(json.dumps({"profile_pass": True, "steps": args.steps, "warmup": args.warmup, "hip_graph": use_graph,
-                              "ms_per_step": 1e3 * dt / args.steps, "value": cells / dt}))
+            emit({"profile_pass": True, "steps": args.steps, "warmup": args.warmup, "hip_graph": use_graph,
+                              "ms_per_step": 1e3 * dt / args.steps, "value": cells / dt})
         if dp:
             dist.destroy_process_group()
         return
@@ -423,7 +436,7 @@ def main():
         }
         if not args.no_cpu_baseline and not dp:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        emit(out)
     if dp:
         dist.destroy_process_group()
 
