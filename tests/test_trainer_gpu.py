@@ -189,3 +189,28 @@ def test_surgery_fine_tune_matches_the_reference():
         else:
             assert torch.equal(got, expanded[k]), k
     assert moved == len(meta["trainable"]) == 3
+
+
+def test_device_index_stream_follows_the_sampling_weights():
+    """rng="device": an epoch's rows are drawn with replacement by inverting the cached cumulative distribution of the
+    stratifier weights -- zero-weight rows never appear, frequencies follow the weights, epochs differ."""
+    from celligner2_amd.trainer import _Loader
+
+    class DS:
+        device = torch.device("cuda", 0)
+
+        def __len__(self):
+            return 1000
+
+    w = torch.zeros(1000, dtype=torch.float64)
+    w[100:200] = 1.0
+    w[500:600] = 3.0
+    ld = _Loader(DS(), 128, weights=w, num_samples=200000, rng="device")
+    torch.manual_seed(3)
+    a, b = ld._indices(), ld._indices()
+    assert a.shape == (200000,) and a.dtype == torch.int64 and not torch.equal(a, b)
+    cnt = torch.bincount(a, minlength=1000).double().cpu()
+    assert cnt[w == 0].sum() == 0
+    lo, hi = cnt[100:200].sum().item(), cnt[500:600].sum().item()
+    assert abs(lo / 200000 - 0.25) < 0.01 and abs(hi / 200000 - 0.75) < 0.01
+    assert cnt[100:200].min() > 300 and cnt[500:600].max() < 1900  # 500 and 1500 expected per row
