@@ -38,6 +38,8 @@ CONFIGS = {
                desc="synthetic 100k x 19k, hidden [1024,512], latent 64, NB + MMD, 3 conditions"),
     "c2": dict(G=19000, hidden=[256, 128], latent=16, C=2, P=30, cls_hidden=[32, 64], B=128, N=11400, beta=500.0,
                desc="CCLE+TCGA shape 11.4k x 19k, hidden [256,128], latent 16, NB + MMD + classifier"),
+    "c4z": dict(G=19000, hidden=[1024, 512], latent=64, C=3, P=0, cls_hidden=[32], B=4096, N=100000, beta=1.0, recon="zinb",
+                desc="c4 with the ZINB reconstruction (second gene-width head for the dropout logits)"),
     # the other configurations of SURVEY.md 8(d): records kept under profiles/, not the headline
     "c1": dict(G=1000, hidden=[128, 128], latent=10, C=5, P=0, cls_hidden=[32], B=128, N=15681, beta=1.0, recon="mse",
                desc="pancreas shape 15.7k x 1000, hidden [128,128], latent 10, MSE on log1p counts + MMD, 5 conditions"),

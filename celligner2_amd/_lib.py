@@ -66,6 +66,8 @@ _SIGS = {
     "c2_recon_nb_fwd_bwd_dbias": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]),
     "c2_recon_zinb_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, vp, i32, i64,
                                     i64, vp, vp, vp, vp, vp]),
+    "c2_recon_zinb_fwd_bwd_rc": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, vp, i32,
+                                       i64, i64, vp, vp, vp, vp, vp, vp]),
     "c2_nb_row_const": (i32, [vp, i64, vp, i64, i64, i64, vp, vp]),
     "c2_recon_mse_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, f32, vp, vp, i32, i64, vp, vp]),
     "c2_classifier_loss_fwd_bwd": (i32, [vp, i64, vp, i64, i32, f32, vp, vp, i32, i64, vp, vp]),

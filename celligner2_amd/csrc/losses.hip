@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(NT) void zinb_fwd_bwd_kernel(NbArgs a, ZinbExtra z)
                 dpi = -sg + sigmoid_f(-pv);
             } else if (x > eps) {
                 const float zt = x + th;
-                ll = tk1[c] - zt * ltm + x * logf(mu + eps) + lgamma_pos(zt) - lgamma_pos(x + 1.0f) - pv - sp;
+                ll = tk1[c] - zt * ltm + x * logf(mu + eps) + lgamma_pos(zt) - (a.lgx ? 0.f : lgamma_pos(x + 1.0f)) - pv - sp;
                 dmu_mu = x * mu / (mu + eps) - zt * mu / tm;
                 dth = tk2[c] - ltm - zt / tm + digamma_pos(zt);
                 dpi = -sigmoid_f(pv);
@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(NT) void zinb_fwd_bwd_kernel(NbArgs a, ZinbExtra z)
             dacc[c] += m ? scale * tth[c] * dth : 0.f;
             loss_acc += m ? ll : 0.f;
         }
+        if (a.lgx && tid == 0) loss_acc -= a.lgx[row];
     }
     if (cur_pat >= 0) flush(cur_pat);
     loss_acc = block_sum<NT>(loss_acc, red);
@@ -1138,6 +1139,7 @@ __global__ void zinb_table_kernel(const float* __restrict__ theta, int C, int64_
 
 struct ZinbGene { float ll, dmu_mu, dth, dpi; };
 // one gene: mu = sizefactor * softmax, th / lte / k1 / k2 from the table, x the count, pv the dropout logit
+template <bool HAS_LGX>  // the caller subtracts the row's sum of lgamma(x + 1) itself (a constant of the data)
 __device__ __forceinline__ ZinbGene zinb_gene(float mu, float th, float lte, float k1, float k2, float x, float pv) {
     const float eps = 1e-8f;
     const float tm = th + mu + eps;
@@ -1169,7 +1171,7 @@ __device__ __forceinline__ ZinbGene zinb_gene(float mu, float th, float lte, flo
     lgam_digam_fast(zt, lg, dg);
     const float mue = mu + eps;
     ZinbGene ct;
-    ct.ll = k1 - zt * ltm + x * flog(mue) + lg - lgamma_fast(x + 1.0f) - pv - sp;
+    ct.ll = k1 - zt * ltm + x * flog(mue) + lg - (HAS_LGX ? 0.f : lgamma_fast(x + 1.0f)) - pv - sp;
     ct.dmu_mu = x * mu * frcp(mue) - zt * mu * rtm;
     ct.dth = k2 - ltm - zt * rtm + dg;
     ct.dpi = -sig_p;
@@ -1182,7 +1184,7 @@ __device__ __forceinline__ ZinbGene zinb_gene(float mu, float th, float lte, flo
     return o;
 }
 
-template <typename TD, int NT, int NV>
+template <typename TD, int NT, int NV, bool HAS_LGX>
 __global__ __launch_bounds__(NT) void zinb_rowreg_kernel(NbArgs a, ZinbExtra z) {
     extern __shared__ __attribute__((aligned(16))) float dacc[];  // [NV][NT] chunks of four: d(theta) accumulator
     __shared__ float red[32];
@@ -1288,7 +1290,7 @@ __global__ __launch_bounds__(NT) void zinb_rowreg_kernel(NbArgs a, ZinbExtra z) 
 #pragma unroll
                         for (int k = k2; k < k2 + 2; ++k) {
                             const bool m = (cm >> (8 * k)) & 0xffu;
-                            const ZinbGene gq = zinb_gene(ev[i][k] * cmu, c0[k], c1[k], c2[k], c3[k], cx[k], cp[k]);
+                            const ZinbGene gq = zinb_gene<HAS_LGX>(ev[i][k] * cmu, c0[k], c1[k], c2[k], c3[k], cx[k], cp[k]);
                             const float pgk = m ? scale * gq.dmu_mu : 0.f;
                             pg[i][k] = pgk;
                             S += pgk;
@@ -1312,6 +1314,7 @@ __global__ __launch_bounds__(NT) void zinb_rowreg_kernel(NbArgs a, ZinbExtra z) 
             }
         }
         S = nb_block_reduce<false, NT>(S, red, red_half);
+        if (HAS_LGX && tid == 0) loss_acc -= a.lgx[row];
         const float pS = inv_sum * S;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -1592,12 +1595,12 @@ extern "C" int c2_recon_nb_fwd_bwd_dbias(const float* logits, int64_t ldl, const
                         dl_dtype, lddl, dtheta, ws, status_dev, lgx1_rowsum, row_index, dbias, stream);
 }
 
-extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
+static int recon_zinb_run(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
                                      int64_t ldx, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
                                      const float* theta, const int64_t* cond, int C, int64_t B, int64_t G, float inv_B,
                                      float* loss_out, void* dlogits, void* dpi, int d_dtype, int64_t lddl,
                                      int64_t lddpi, float* dtheta, float* ws, int32_t* status_dev,
-                                     const int64_t* row_index, void* stream) {
+                                     const int64_t* row_index, const float* lgx1_rowsum, void* stream) {
     C2_CHECK(logits && pi && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dpi && dtheta && ws &&
                  status_dev, "null pointer");
     C2_CHECK(d_dtype == C2_F32 || d_dtype == C2_BF16, "bad dtype");
@@ -1622,18 +1625,20 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
         hipLaunchKernelGGL(zinb_table_kernel, dim3((unsigned)(Gp / 256)), dim3(256), 0, st, theta, C, G, Gp, tab, cond, B,
                            rowflags);
         NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-                 nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags, nullptr};
+                 lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B, rowflags, nullptr};
+#define ZINB_K(TD, NT, NV, LGX)                                                                               \
+    do {                                                                                                      \
+        auto k = zinb_rowreg_kernel<TD, NT, NV, LGX>;                                                          \
+        if (l > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+        hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), l, st, a, z);                                           \
+    } while (0)
 #define ZINB_F(NT, NV)                                                                                        \
     if (f.nt == NT && f.nv == NV) {                                                                           \
         const size_t l = (size_t)NT * NV * 16;                                                                \
         if (d_dtype == C2_BF16) {                                                                             \
-            auto k = zinb_rowreg_kernel<bf16_t, NT, NV>;                                                       \
-            if (l > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
-            hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), l, st, a, z);                                       \
+            if (lgx1_rowsum) ZINB_K(bf16_t, NT, NV, true); else ZINB_K(bf16_t, NT, NV, false);                 \
         } else {                                                                                              \
-            auto k = zinb_rowreg_kernel<float, NT, NV>;                                                        \
-            if (l > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
-            hipLaunchKernelGGL(k, dim3(ngroups), dim3(NT), l, st, a, z);                                       \
+            if (lgx1_rowsum) ZINB_K(float, NT, NV, true); else ZINB_K(float, NT, NV, false);                   \
         }                                                                                                     \
     }
         ZINB_F(128, 2)
@@ -1644,11 +1649,12 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
         ZINB_F(512, 8)
         ZINB_F(512, 10)
 #undef ZINB_F
+#undef ZINB_K
     } else {
     hipLaunchKernelGGL(nb_table_kernel, dim3((unsigned)(nb_tab_ld(G) / 256)), dim3(256), 0, st, theta, C, G, nb_tab_ld(G), tab,
                        (const int64_t*)nullptr, (int64_t)0, (int*)nullptr, (int32_t*)nullptr);
     NbArgs a{logits, x, goodloc, sizefactor, cond, tab, dlogits, part_dt, part_flag, part_loss, status_dev,
-             nullptr, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
+             lgx1_rowsum, row_index, ldl, ldx, ldg, lddl, B, G, C, inv_B};
     const size_t lds = (size_t)G * sizeof(float);
     constexpr int NT = 512;
     if (d_dtype == C2_BF16) {
@@ -1669,6 +1675,27 @@ extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const flo
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
+                                     int64_t ldx, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                                     const float* theta, const int64_t* cond, int C, int64_t B, int64_t G, float inv_B,
+                                     float* loss_out, void* dlogits, void* dpi, int d_dtype, int64_t lddl,
+                                     int64_t lddpi, float* dtheta, float* ws, int32_t* status_dev,
+                                     const int64_t* row_index, void* stream) {
+    return recon_zinb_run(logits, ldl, pi, ldpi, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out,
+                          dlogits, dpi, d_dtype, lddl, lddpi, dtheta, ws, status_dev, row_index, nullptr, stream);
+}
+
+extern "C" int c2_recon_zinb_fwd_bwd_rc(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x,
+                                        int64_t ldx, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                                        const float* theta, const int64_t* cond, int C, int64_t B, int64_t G, float inv_B,
+                                        float* loss_out, void* dlogits, void* dpi, int d_dtype, int64_t lddl,
+                                        int64_t lddpi, float* dtheta, float* ws, int32_t* status_dev,
+                                        const int64_t* row_index, const float* lgx1_rowsum, void* stream) {
+    C2_CHECK(lgx1_rowsum, "null pointer");
+    return recon_zinb_run(logits, ldl, pi, ldpi, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out,
+                          dlogits, dpi, d_dtype, lddl, lddpi, dtheta, ws, status_dev, row_index, lgx1_rowsum, stream);
 }
 
 extern "C" int c2_nb_row_const(const float* x, int64_t ldx, const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G,

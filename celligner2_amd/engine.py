@@ -813,7 +813,7 @@ class StepEngine:
                 xs, gl, ridx = x, batch["goodloc"], None
             ops.recon_zinb(logits, pi, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
                            losses[0:1], dlogits, dpi, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
-                           row_index=ridx)
+                           row_index=ridx, lgx1=batch.get("lgx1"))
         # ---- classifier
         classes = batch.get("classes")
         self._has_cls = classes is not None

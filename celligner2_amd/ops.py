@@ -451,7 +451,7 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
 
 
 def recon_zinb(logits, pi, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogits, dpi, dtheta, ws, status,
-               row_index=None):
+               row_index=None, lgx1=None):
     L.require_gpu(logits, pi, x, goodloc, dlogits, dpi)
     B, G = logits.shape
     C = theta.shape[1]
@@ -460,11 +460,15 @@ def recon_zinb(logits, pi, x, goodloc, sizefactor, theta, cond, inv_B, loss_out,
     assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
     assert ws.numel() >= recon_nb_ws(B, G, C) and sizefactor.dtype == torch.float32 and sizefactor.is_contiguous()
     assert x.shape[1] == G and goodloc.shape == x.shape and (row_index is not None or x.shape[0] == B)
-    check(lib.c2_recon_zinb_fwd_bwd(ptr(logits), _row_major(logits, "logits"), ptr(pi), _row_major(pi, "pi"), ptr(x),
-                                    _row_major(x, "x"), ptr(goodloc), _row_major(goodloc, "goodloc"), ptr(sizefactor),
-                                    ptr(theta), ptr(cond), C, B, G, float(inv_B), ptr(loss_out), ptr(dlogits), ptr(dpi),
-                                    dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"), _row_major(dpi, "dpi"),
-                                    ptr(dtheta), ptr(ws), ptr(status), ptr(row_index), stream()))
+    args = (ptr(logits), _row_major(logits, "logits"), ptr(pi), _row_major(pi, "pi"), ptr(x), _row_major(x, "x"),
+            ptr(goodloc), _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta), ptr(cond), C, B, G, float(inv_B),
+            ptr(loss_out), ptr(dlogits), ptr(dpi), dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"),
+            _row_major(dpi, "dpi"), ptr(dtheta), ptr(ws), ptr(status), ptr(row_index))
+    if lgx1 is not None:  # the per-row sum of goodloc * lgamma(x + 1), evaluated once per dataset (nb_row_const)
+        assert lgx1.dtype == torch.float32 and lgx1.is_contiguous() and lgx1.numel() == B
+        check(lib.c2_recon_zinb_fwd_bwd_rc(*args, ptr(lgx1), stream()))
+    else:
+        check(lib.c2_recon_zinb_fwd_bwd(*args, stream()))
 
 
 def recon_mse(logits, x, goodloc, inv_B, loss_out, dlogits, ws):

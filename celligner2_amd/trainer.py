@@ -342,7 +342,9 @@ class Trainer:
         log_in = model.applylog and model.recon_loss != "mse"
         if not log_in and xin_dtype == torch.float32:
             xin_dtype = None  # the encoder reads x itself
-        nb = model.recon_loss == "nb"
+        # NB and ZINB read the batch's counts and mask where the dataset lives and take the data-only term
+        # sum goodloc * lgamma(x + 1) per row from the dataset (lgamma(1) = 0: the same constant serves both)
+        nb = model.recon_loss in ("nb", "zinb")
         G, H0 = model.input_dim, model.hidden_layer_sizes[0]
 
         def in_place(n):  # both first-layer GEMMs (forward [n,H0] over G, weight gradient [H0,G] over n) on the 256x256 kernel

@@ -201,6 +201,15 @@ int c2_recon_zinb_fwd_bwd(const float* logits, int64_t ldl, const float* pi, int
                           void* dpi, int d_dtype, int64_t lddl, int64_t lddpi, float* dtheta, float* ws,
                           int32_t* status_dev, const int64_t* row_index, void* stream);
 
+/* c2_recon_zinb_fwd_bwd with the data-only term handed in: lgx1_rowsum[b] = sum_g goodloc * lgamma(x + 1) of batch row b
+ * (c2_nb_row_const; a zero count adds lgamma(1) = 0, so the NB path's per-row constant is also the ZINB one) -- the kernel
+ * then evaluates no lgamma(x + 1).  Serves a device-resident dataset; no counterpart in the reference. */
+int c2_recon_zinb_fwd_bwd_rc(const float* logits, int64_t ldl, const float* pi, int64_t ldpi, const float* x, int64_t ldx,
+                             const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
+                             const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits,
+                             void* dpi, int d_dtype, int64_t lddl, int64_t lddpi, float* dtheta, float* ws,
+                             int32_t* status_dev, const int64_t* row_index, const float* lgx1_rowsum, void* stream);
+
 /* out[b] = sum_g goodloc[b][g] * lgamma(x[b][g] + 1): the data-only term of the NB log-likelihood
  * (losses.py:60-64, `- torch.lgamma(x + 1)`), for c2_recon_nb_fwd_bwd's lgx1_rowsum. */
 int c2_nb_row_const(const float* x, int64_t ldx, const uint8_t* goodloc, int64_t ldg, int64_t B, int64_t G,

@@ -776,6 +776,14 @@ def test_recon_zinb(B, G, C, multi, d_dtype):
                    row_index=T(perm.astype(np.int64)))
     assert loss2.item() == loss.item()
     assert torch.equal(dl2, dl) and torch.equal(dpi2, dpi) and torch.equal(dth2, dth)
+    # the data-only term sum goodloc * lgamma(x + 1) handed in (c2_recon_zinb_fwd_bwd_rc): same loss, identical gradients
+    lgx = ops.nb_row_const(T(x), T(good))
+    loss3 = torch.zeros(1, device=DEV)
+    dl3, dpi3, dth3 = torch.empty_like(dl), torch.empty_like(dpi), torch.empty_like(dth)
+    ops.recon_zinb(T(o), T(pi), T(x), T(good), T(sf), T(theta), T(cond), 1.0 / B, loss3, dl3, dpi3, dth3, ws, status,
+                   lgx1=lgx)
+    assert abs(loss3.item() - recon64) < 1e-4 * abs(recon64)
+    assert torch.equal(dl3, dl) and torch.equal(dpi3, dpi) and torch.equal(dth3, dth)
 
 
 def test_recon_zinb_row_walk_and_bad_rows():
