@@ -62,9 +62,9 @@ __device__ __forceinline__ int xc_half(int k) {
     return BX == 256 ? ((k >> 3) & 1) : 0;
 }
 
-template <bool RC, int BX>
+template <bool RC, int BX, int PPW = 4>  // PPW: LDS-DMA pieces (1 KB) of an operand tile that one wave moves
 __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot, int wave, int lane) {
-    const int i = 4 * wave + j;
+    const int i = PPW * wave + j;
     if (RC) {
         const int row = 8 * i + (lane >> 3), p = lane & 7;
         const int c = p ^ ((row >> 1) & 7);
@@ -81,9 +81,9 @@ __device__ __forceinline__ int stage_offset(int j, int64_t ld, int x0, int xtot,
 }
 
 // First reduction index (inside the K-tile) of the chunk that lane `lane` moves in instruction j.
-template <bool RC, int BX>
+template <bool RC, int BX, int PPW = 4>
 __device__ __forceinline__ int stage_k(int j, int wave, int lane) {
-    const int i = 4 * wave + j;
+    const int i = PPW * wave + j;
     if (RC) {
         const int row = 8 * i + (lane >> 3), p = lane & 7;
         return (p ^ ((row >> 1) & 7)) * 8;
@@ -96,24 +96,24 @@ __device__ __forceinline__ int stage_k(int j, int wave, int lane) {
 // reaches m0 through scalar arithmetic instead of a v_readfirstlane per instruction.  The source address is formed
 // as (uniform base) + zext(32-bit per-lane BYTE offset), the shape the backend turns into the scalar-base form of the
 // instruction (global_load_lds_dwordx4 v_off, s[base:base+1]) -- no 64-bit vector add per instruction.
-template <int J0, int J1>
+template <int J0, int J1, int PPW = 4>
 __device__ __forceinline__ void stage_dma(const bf16_t* base, const int (&voff)[4], char* tile, int wave) {
     const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
     for (int j = J0; j < J1; ++j)
         __builtin_amdgcn_global_load_lds((g_void*)(b + (uint64_t)((uint32_t)voff[j] * 2u)),
-                                         (lds_void*)(tile + (4 * wave + j) * 1024), 16, 0, 0);
+                                         (lds_void*)(tile + (PPW * wave + j) * 1024), 16, 0, 0);
 }
 
 // Last, partial K-tile: same image through registers, reduction indices >= kvalid are zero.
-template <bool RC, int BX>
+template <bool RC, int BX, int PPW = 4>
 __device__ __forceinline__ void stage_tail(const bf16_t* base, const int (&voff)[4], char* tile, int wave, int lane,
                                            int kvalid) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PPW; ++j) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (stage_k<RC, BX>(j, wave, lane) < kvalid) v = *reinterpret_cast<const u32x4*>(base + voff[j]);
-        *reinterpret_cast<u32x4*>(tile + (4 * wave + j) * 1024 + lane * 16) = v;
+        if (stage_k<RC, BX, PPW>(j, wave, lane) < kvalid) v = *reinterpret_cast<const u32x4*>(base + voff[j]);
+        *reinterpret_cast<u32x4*>(tile + (PPW * wave + j) * 1024 + lane * 16) = v;
     }
 }
 
@@ -588,9 +588,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
 // each with its own pair of tiles), and a third as many barrier / LDS-DMA round trips, which is what bounds the
 // narrow layers (one 128x128 block per CU, 24 K-tiles of 16 MFMAs each before).  128x128 tile, 4 waves (2 x 2), each
 // wave 64x64; two stages of four slots (128 KB): while K-tile T is multiplied, T+1 is in flight.
-template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, int tiles_n) {
-    constexpr int NW = 4, BX = 128, MI = 2, WN = 2;
+// NWX = 8 (default, C2_X3_WAVES=4 for A/B): eight waves (4 x 2) of 32x64 -- an LDS-DMA instruction holds the issuing wave
+// for ~100 cycles, and with four waves each one issues sixteen of them per K-tile, longer than its 48 MFMAs take; eight
+// waves issue eight each, two waves per SIMD: ~10 % faster on every narrow shape (22.3 -> 20.1 us at 4096 x 512 x 1024).
+// (Measured and not kept: the next tile's DMA issued one operand tile per reduction step in front of that step's MFMAs
+// instead of all up front: 20.1 -> 22.3 us, 29.6 -> 37.8 us on the 1024-wide input gradient.)
+template <bool A_RC, bool B_RC, int NWX>
+__global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int BX = 128, MI = NWX == 8 ? 1 : 2, WN = 2, PPW = 16 / NWX;
     constexpr int TILE_BYTES = BX * BK * 2;  // 16 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -630,9 +635,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
     const bf16_t* pBl = reinterpret_cast<const bf16_t*>(a.B_lo) + offB;
     int voa[4], vob[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        voa[j] = stage_offset<A_RC, BX>(j, a.lda, m0, a.M, wave, lane);
-        vob[j] = stage_offset<B_RC, BX>(j, a.ldb, n0, a.N, wave, lane);
+    for (int j = 0; j < PPW; ++j) {
+        voa[j] = stage_offset<A_RC, BX, PPW>(j, a.lda, m0, a.M, wave, lane);
+        vob[j] = stage_offset<B_RC, BX, PPW>(j, a.ldb, n0, a.N, wave, lane);
     }
     const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
     const int64_t stepB = B_RC ? BK : (int64_t)BK * a.ldb;
@@ -649,15 +654,15 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
     auto issue = [&](int t, int s) {
         char* d = smem + 4 * s * TILE_BYTES;
         if (t < nfull) {
-            stage_dma<0, 4>(pAh, voa, d, wave_u);
-            stage_dma<0, 4>(pBh, vob, d + TILE_BYTES, wave_u);
-            stage_dma<0, 4>(pAl, voa, d + 2 * TILE_BYTES, wave_u);
-            stage_dma<0, 4>(pBl, vob, d + 3 * TILE_BYTES, wave_u);
+            stage_dma<0, PPW, PPW>(pAh, voa, d, wave_u);
+            stage_dma<0, PPW, PPW>(pBh, vob, d + TILE_BYTES, wave_u);
+            stage_dma<0, PPW, PPW>(pAl, voa, d + 2 * TILE_BYTES, wave_u);
+            stage_dma<0, PPW, PPW>(pBl, vob, d + 3 * TILE_BYTES, wave_u);
         } else {  // the partial last tile: through registers, zero filled
-            stage_tail<A_RC, BX>(pAh, voa, d, wave, lane, ktail);
-            stage_tail<B_RC, BX>(pBh, vob, d + TILE_BYTES, wave, lane, ktail);
-            stage_tail<A_RC, BX>(pAl, voa, d + 2 * TILE_BYTES, wave, lane, ktail);
-            stage_tail<B_RC, BX>(pBl, vob, d + 3 * TILE_BYTES, wave, lane, ktail);
+            stage_tail<A_RC, BX, PPW>(pAh, voa, d, wave, lane, ktail);
+            stage_tail<B_RC, BX, PPW>(pBh, vob, d + TILE_BYTES, wave, lane, ktail);
+            stage_tail<A_RC, BX, PPW>(pAl, voa, d + 2 * TILE_BYTES, wave, lane, ktail);
+            stage_tail<B_RC, BX, PPW>(pBl, vob, d + 3 * TILE_BYTES, wave, lane, ktail);
         }
         pAh += stepA; pAl += stepA; pBh += stepB; pBl += stepB;
     };
@@ -680,8 +685,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ah[i] = read_frag<A_RC, BX>(tAh, wm * 64 + i * 32, ks, lane);
-                al[i] = read_frag<A_RC, BX>(tAl, wm * 64 + i * 32, ks, lane);
+                ah[i] = read_frag<A_RC, BX>(tAh, wm * (MI * 32) + i * 32, ks, lane);
+                al[i] = read_frag<A_RC, BX>(tAl, wm * (MI * 32) + i * 32, ks, lane);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
     asm volatile("" ::: "memory");
     const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
     float* C = a.C + (int64_t)split * a.slab_stride;
-    float* wl = reinterpret_cast<float*>(smem + wave * 16384);
+    float* wl = reinterpret_cast<float*>(smem + wave * (MI * 8192));  // [MI * 32 rows][64 cols] fp32, private to the wave
     const int col4 = n0 + wn * 64 + (lane & 15) * 4;
     const bool vec_ok = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (col4 + 4 <= a.N);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
             if (col4 + c < a.N) bv[c] = a.bias[col4 + c];
     }
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < MI; ++ii)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -720,10 +725,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmArgs a, int tiles_m, i
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
+    for (int rr = 0; rr < MI * 8; ++rr) {
         const int r = rr * 4 + (lane >> 4);
         f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
-        const int row = m0 + wm * 64 + r;
+        const int row = m0 + wm * (MI * 32) + r;
         if (row < a.M) {
             float* dst = C + (int64_t)row * a.ldc + col4;
             if (vec_ok) {
@@ -819,7 +824,8 @@ int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t 
     return 0;
 }
 
-static void launch_x3(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+template <int NWX>
+static void launch_x3_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
     using namespace wide;
     constexpr int BX = 128;
     constexpr int LDS = 8 * BX * BK * 2;  // two stages of four 16 KB slots
@@ -827,17 +833,22 @@ static void launch_x3(int layout, const GemmArgs& a, int nslab, hipStream_t stre
     const dim3 grid(tiles_m * tiles_n * nslab);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, true, NWX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<true, false, NWX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<false, false, NWX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     if (layout == 0)
-        hipLaunchKernelGGL((gemm_x3_kernel<true, true>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_x3_kernel<true, true, NWX>), grid, dim3(64 * NWX), LDS, stream, a, tiles_m, tiles_n);
     else if (layout == 1)
-        hipLaunchKernelGGL((gemm_x3_kernel<true, false>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_x3_kernel<true, false, NWX>), grid, dim3(64 * NWX), LDS, stream, a, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_x3_kernel<false, false>), grid, dim3(256), LDS, stream, a, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_x3_kernel<false, false, NWX>), grid, dim3(64 * NWX), LDS, stream, a, tiles_m, tiles_n);
+}
+static void launch_x3(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+    static const bool four = []() { const char* e = getenv("C2_X3_WAVES"); return e && e[0] == '4'; }();
+    if (four) launch_x3_nw<4>(layout, a, nslab, stream);
+    else launch_x3_nw<8>(layout, a, nslab, stream);
 }
 
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {
