@@ -588,14 +588,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
 // each with its own pair of tiles), and a third as many barrier / LDS-DMA round trips, which is what bounds the
 // narrow layers (one 128x128 block per CU, 24 K-tiles of 16 MFMAs each before).  128x128 tile, 4 waves (2 x 2), each
 // wave 64x64; two stages of four slots (128 KB): while K-tile T is multiplied, T+1 is in flight.
-// NWX = 8 (default, C2_X3_WAVES=4 for A/B): eight waves (4 x 2) of 32x64 -- an LDS-DMA instruction holds the issuing wave
-// for ~100 cycles, and with four waves each one issues sixteen of them per K-tile, longer than its 48 MFMAs take; eight
-// waves issue eight each, two waves per SIMD: ~10 % faster on every narrow shape (22.3 -> 20.1 us at 4096 x 512 x 1024).
+// NWX = 16 (default; C2_X3_WAVES=4 / 8 for A/B): an LDS-DMA instruction holds the issuing wave for ~100 cycles, and with
+// four waves of 64x64 each one issues sixteen of them per K-tile, longer than its 48 MFMAs take.  Eight waves of 32x64
+// issue eight each, two waves per SIMD: ~10 % faster on every narrow shape (22.3 -> 20.1 us at 4096 x 512 x 1024, C4 step
+// 1.840 -> 1.810 ms); sixteen waves of 32x32 issue four each, four waves per SIMD: a further 1-9 % per launch (19.8 us;
+// 29.6 -> 27.0 us on the 1024-wide input gradient; C4 step 1.836 -> 1.829 ms on the box that compared them).
 // (Measured and not kept: the next tile's DMA issued one operand tile per reduction step in front of that step's MFMAs
 // instead of all up front: 20.1 -> 22.3 us, 29.6 -> 37.8 us on the 1024-wide input gradient.)
 template <bool A_RC, bool B_RC, int NWX>
 __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles_m, int tiles_n) {
-    constexpr int BX = 128, MI = NWX == 8 ? 1 : 2, WN = 2, PPW = 16 / NWX;
+    // waves: 4 = 2 x 2 of 64x64, 8 = 4 x 2 of 32x64, 16 = 4 x 4 of 32x32
+    constexpr int BX = 128, MI = NWX == 4 ? 2 : 1, NJ = NWX == 16 ? 1 : 2, WN = NWX == 16 ? 4 : 2, PPW = 16 / NWX;
+    constexpr int WCOLS = NJ * 32;
     constexpr int TILE_BYTES = BX * BK * 2;  // 16 KB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -642,11 +646,11 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
     const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
     const int64_t stepB = B_RC ? BK : (int64_t)BK * a.ldb;
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -677,11 +681,11 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
         const char *tAh = d, *tBh = d + TILE_BYTES, *tAl = d + 2 * TILE_BYTES, *tBl = d + 3 * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+            bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = read_frag<B_RC, BX>(tBh, wn * 64 + j * 32, ks, lane);
-                bl[j] = read_frag<B_RC, BX>(tBl, wn * 64 + j * 32, ks, lane);
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = read_frag<B_RC, BX>(tBh, wn * WCOLS + j * 32, ks, lane);
+                bl[j] = read_frag<B_RC, BX>(tBl, wn * WCOLS + j * 32, ks, lane);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -705,8 +709,9 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
     asm volatile("" ::: "memory");
     const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
     float* C = a.C + (int64_t)split * a.slab_stride;
-    float* wl = reinterpret_cast<float*>(smem + wave * (MI * 8192));  // [MI * 32 rows][64 cols] fp32, private to the wave
-    const int col4 = n0 + wn * 64 + (lane & 15) * 4;
+    constexpr int LPR = WCOLS / 4, RPP = 64 / LPR;  // lanes per row of the wave tile, rows per pass of 64 lanes
+    float* wl = reinterpret_cast<float*>(smem + wave * (MI * 32 * WCOLS * 4));  // [MI * 32 rows][WCOLS] fp32, wave-private
+    const int col4 = n0 + wn * WCOLS + (lane % LPR) * 4;
     const bool vec_ok = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (col4 + 4 <= a.N);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
@@ -717,17 +722,17 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
 #pragma unroll
     for (int ii = 0; ii < MI; ++ii)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                wl[r * 64 + j * 32 + (lane & 31)] = acc[ii][j][e];
+                wl[r * WCOLS + j * 32 + (lane & 31)] = acc[ii][j][e];
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int rr = 0; rr < MI * 8; ++rr) {
-        const int r = rr * 4 + (lane >> 4);
-        f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
+    for (int rr = 0; rr < MI * 32 / RPP; ++rr) {
+        const int r = rr * RPP + lane / LPR;
+        f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * WCOLS + (lane % LPR) * 4);
         const int row = m0 + wm * (MI * 32) + r;
         if (row < a.M) {
             float* dst = C + (int64_t)row * a.ldc + col4;
@@ -846,9 +851,10 @@ static void launch_x3_nw(int layout, const GemmArgs& a, int nslab, hipStream_t s
         hipLaunchKernelGGL((gemm_x3_kernel<false, false, NWX>), grid, dim3(64 * NWX), LDS, stream, a, tiles_m, tiles_n);
 }
 static void launch_x3(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
-    static const bool four = []() { const char* e = getenv("C2_X3_WAVES"); return e && e[0] == '4'; }();
-    if (four) launch_x3_nw<4>(layout, a, nslab, stream);
-    else launch_x3_nw<8>(layout, a, nslab, stream);
+    static const int waves = []() { const char* e = getenv("C2_X3_WAVES"); return e ? atoi(e) : 16; }();
+    if (waves == 4) launch_x3_nw<4>(layout, a, nslab, stream);
+    else if (waves == 8) launch_x3_nw<8>(layout, a, nslab, stream);
+    else launch_x3_nw<16>(layout, a, nslab, stream);
 }
 
 int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream) {
