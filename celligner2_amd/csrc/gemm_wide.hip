@@ -581,6 +581,321 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     }
 }
 
+// ---- sixteen waves (4 x 4) of 64x64 on the same 256x256 tile and ring: an LDS-DMA instruction holds the issuing wave for
+// ~100 cycles; eight waves issue eight per K-tile each, sixteen issue four and leave three partner waves per SIMD to cover
+// them.  128 registers per wave: 64 accumulators, fragments single-buffered.  Layouts with a row-wise operand only.
+template <int PPW>
+__device__ __forceinline__ void wait_pieces(int c) {  // all but the c newest operand-tile loads (PPW pieces each) have landed
+    static_assert(PPW == 2, "counted waits are written out for two pieces per tile");
+    switch (c) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+template <bool A_RC, bool B_RC, int BX, typename F>
+__device__ __forceinline__ void compute_tile16_64(const char* tA, const char* tB, int wm, int wn, int lane,
+                                                  f32x4 (&acc)[4][4], F&& piece) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag16<B_RC, BX>(tB, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag16<A_RC, BX>(tA, wm * 64 + i * 16, ks, lane);
+        piece(2 * ks);
+        piece(2 * ks + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+template <bool A_RC, bool B_RC, int IDX = 0>
+__global__ __launch_bounds__(1024) void gemm_wide16_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    static_assert(IDX == 0 || (IDX == 1 && A_RC) || (IDX == 2 && !B_RC), "row index on an RC A or an XC B operand");
+    static_assert(A_RC || B_RC, "the sixteen-wave form multiplies on 16x16x32: one operand read row-wise");
+    constexpr int BX = 256, PPW = 2;        // block tile edge; LDS-DMA pieces of an operand tile per wave
+    constexpr int D = 2;
+    constexpr int NSLOT = 2 * D + 1;
+    constexpr int WN = 4;                   // waves along N (4 x 4 waves of 64x64)
+    constexpr int TILE_BYTES = BX * BK * 2; // one operand tile = one ring slot
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // the same number, known to be wave-uniform
+    const int wm = wave / WN, wn = wave % WN;
+#if C2_GEMM_DBG & 16
+    const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
+#endif
+
+    // ---- workgroup -> (split, tile) with the blocks of one XCD on a compact panel
+    int wg;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tiles = tiles_m * tiles_n;
+    const int split = wg / tiles;
+    int tm, tn;
+    {
+        const int t = wg - split * tiles;
+        const int per = GROUP_M * tiles_n;
+        const int gid = t / per, first = gid * GROUP_M;
+        const int gsz = min(tiles_m - first, GROUP_M);
+        const int u = t - gid * per;
+        tm = first + u % gsz;
+        tn = u / gsz;
+    }
+    const int m0 = tm * BX, n0 = tn * BX;
+    const int rbeg = split * a.r_per_split;
+    const int rend = min(a.R, rbeg + a.r_per_split);
+    const int rlen = max(rend - rbeg, 0);
+    const int nfull = rlen / BK;
+    const int ktail = rlen - nfull * BK;
+    const int nt1 = nfull + (ktail ? 1 : 0);        // K-tiles of one segment
+    const int nt = a.A_lo ? 3 * nt1 : nt1;          // bf16x3: segments (hi,hi) (hi,lo) (lo,hi)
+
+    // uniform tile bases (scalar registers) + 32-bit per-lane offsets
+    const int64_t offA = IDX == 1 ? (int64_t)rbeg : (A_RC ? (int64_t)m0 * a.lda + rbeg : (int64_t)rbeg * a.lda + m0);
+    const int64_t offB = IDX == 2 ? (int64_t)n0 : (B_RC ? (int64_t)n0 * a.ldb + rbeg : (int64_t)rbeg * a.ldb + n0);
+    const bf16_t* Ah = reinterpret_cast<const bf16_t*>(a.A) + offA;
+    const bf16_t* Bh = reinterpret_cast<const bf16_t*>(a.B) + offB;
+    const bf16_t* Al = reinterpret_cast<const bf16_t*>(a.A_lo) + offA;
+    const bf16_t* Bl = reinterpret_cast<const bf16_t*>(a.B_lo) + offB;
+    int voa[4], vob[4];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        voa[j] = stage_offset<A_RC, BX, PPW>(j, a.lda, m0, a.M, wave, lane);
+        vob[j] = stage_offset<B_RC, BX, PPW>(j, a.ldb, n0, a.N, wave, lane);
+    }
+    const int64_t stepA = A_RC ? BK : (int64_t)BK * a.lda;
+    const int64_t stepB = IDX == 2 ? 0 : (B_RC ? BK : (int64_t)BK * a.ldb);
+    if (IDX == 1) {  // row part of A's offsets: the indexed row instead of the tile row (edge rows re-read the last row)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = 8 * (PPW * wave + j) + (lane >> 3);
+            const int x = min(row, a.M - 1 - m0);
+            voa[j] += (a.rows[m0 + x] - x) * (int)a.lda;
+        }
+    }
+    // IDX 2: vob[j] = rows[k-row] * ldb + xob[j]; the DMA instruction j of this wave covers k-rows 4*wave + 2j + {0,1}
+    int xob[4];
+    int kr[2 * PPW];  // the wave's four row indices of the B tile that is issued next
+    auto load_krows = [&](int t) {
+        const int32_t* rp = a.rows + rbeg + t * BK + 2 * PPW * wave_u;  // wave-uniform address: scalar loads
+#pragma unroll
+        for (int q = 0; q < 2 * PPW; ++q) kr[q] = rp[q];
+    };
+    auto set_vob = [&]() {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) vob[j] = ((lane >> 5) ? kr[2 * j + 1] : kr[2 * j]) * (int)a.ldb + xob[j];
+    };
+    if (IDX == 2) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int k = 2 * PPW * wave + 2 * j + (lane >> 5);
+            xob[j] = vob[j] - k * (int)a.ldb;  // the column part stage_offset<XC> computed
+        }
+    }
+
+    f32x4 acc16[4][4];  // 64x64 wave tile as 4 x 4 tiles of 16x16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- issue state: the next A tile and the next B tile to stage (segment, K-tile inside it, source pointer)
+    const int nseg = a.A_lo ? 3 : 1;
+    int segA = 0, tA = 0, segB = 0, tB = 0;
+    const bf16_t* pA = Ah;
+    const bf16_t* pB = Bh;
+    auto advA = [&]() {
+        ++tA;
+        pA += stepA;
+        if (tA == nt1) { tA = 0; ++segA; pA = (segA == 2) ? Al : Ah; }
+    };
+    auto advB = [&]() {
+        ++tB;
+        pB += stepB;
+        if (tB == nt1) { tB = 0; ++segB; pB = (segB == 1) ? Bl : Bh; }
+    };
+    // generic issue of the next A / B tile into `slot`; q = which half of its 4 DMA instructions (-1: all four).
+    // A partial (tail) tile goes through registers in one piece; past the last segment nothing is issued.
+    auto issueA = [&](int slot, int q) {
+        if ((dbg & 1) || segA >= nseg) return;
+        char* dst = smem + slot * TILE_BYTES;
+        if (tA < nfull) {
+            if (q != 1) stage_dma<0, 1, PPW>(pA, voa, dst, wave_u);
+            if (q != 0) stage_dma<1, 2, PPW>(pA, voa, dst, wave_u);
+        } else if (q <= 0) {
+            stage_tail<A_RC, BX, PPW>(pA, voa, dst, wave, lane, ktail);
+        }
+    };
+    auto issueB = [&](int slot, int q) {
+        if ((dbg & 1) || segB >= nseg) return;
+        if (IDX == 2 && q <= 0) {  // (generic path: index loads not prefetched)
+            load_krows(tB);
+            set_vob();
+        }
+        char* dst = smem + slot * TILE_BYTES;
+        if (tB < nfull) {
+            if (q != 1) stage_dma<0, 1, PPW>(pB, vob, dst, wave_u);
+            if (q != 0) stage_dma<1, 2, PPW>(pB, vob, dst, wave_u);
+        } else if (q <= 0) {
+            stage_tail<B_RC, BX, PPW>(pB, vob, dst, wave, lane, ktail);
+        }
+    };
+    // is virtual K-tile T staged by DMA (a full tile)?
+    auto is_dma = [&](int T) {
+        if (T >= nt) return false;
+        const int t = T - (T >= nt1 ? nt1 : 0) - (T >= 2 * nt1 ? nt1 : 0);
+        return t < nfull;
+    };
+
+    // prologue: loads 0 .. 2D-2 = tiles 0 .. D-2 (A and B) and A of tile D-1, into slots 0 .. 2D-2
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) {
+        issueA(2 * i, -1); advA();
+        issueB(2 * i + 1, -1); advB();
+    }
+    issueA(2 * D - 2, -1); advA();
+
+    // K-tiles [0, nfast): every tile up to D ahead exists and is a full tile -> branch-free steady state
+    const int nfast = max(0, ((ktail == 0) ? nt : (nseg == 1 ? nfull : 0)) - D);
+    int sa = 0;  // slot of A_T; B_T is in the next one
+    auto slot_of = [&](int d) { return sa + d >= NSLOT ? sa + d - NSLOT : sa + d; };
+    int T = 0;
+#if C2_GEMM_DBG & 16
+    unsigned long long wait_clk = 0, bar_clk = 0;
+#endif
+    if (IDX == 2 && nfast > 0) load_krows(tB);
+    for (; T < nfast; ++T) {
+        if (IDX == 2) {
+            set_vob();                                // offsets of the B tile issued in this iteration (tile tB) ...
+            load_krows(min(tB + 1, nt1 - 1));         // ... and the scalar index loads of the next one
+        }
+        // loads 2T and 2T+1 must have landed; the 2D-3 newer ones stay in flight
+#if C2_GEMM_DBG & 16
+        const unsigned long long w0 = clock64();
+#endif
+        wait_pieces<PPW>(2 * D - 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if C2_GEMM_DBG & 16
+        const unsigned long long w1 = clock64();
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if C2_GEMM_DBG & 16
+        wait_clk += w1 - w0;
+        bar_clk += clock64() - w1;
+#endif
+        char* d3 = smem + slot_of(2 * D - 1) * TILE_BYTES;  // the slots tile T-1 occupied: every wave is past
+        char* d4 = smem + slot_of(2 * D) * TILE_BYTES;      // its reads of them
+        auto piece = [&](int p) {
+            if (dbg & 1) return;
+            if (p == 0 && !(dbg & 8)) stage_dma<0, 1, PPW>(pB, vob, d3, wave_u);
+            if (p == 1 && !(dbg & 8)) stage_dma<1, 2, PPW>(pB, vob, d3, wave_u);
+            if (p == 2 && !(dbg & 4)) stage_dma<0, 1, PPW>(pA, voa, d4, wave_u);
+            if (p == 3 && !(dbg & 4)) stage_dma<1, 2, PPW>(pA, voa, d4, wave_u);
+        };
+        if (!(dbg & 2)) {
+            compute_tile16_64<A_RC, B_RC, BX>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc16,
+                                              piece);
+        } else {
+            piece(0); piece(1); piece(2); piece(3);
+        }
+        advB();
+        advA();
+        sa = slot_of(2);
+    }
+    // the rest: tails, segment ends, drain
+    for (; T < nt; ++T) {
+        int inflight = 0;
+#pragma unroll
+        for (int n = 2; n <= 2 * D - 2; ++n) inflight += is_dma(T + (n >> 1)) ? 1 : 0;
+        wait_pieces<PPW>(inflight);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int s3 = slot_of(2 * D - 1), s4 = slot_of(2 * D);
+        auto piece = [&](int p) {
+            if (p < 2) issueB(s3, p);
+            else issueA(s4, p - 2);
+        };
+        if (!(dbg & 2)) {
+            compute_tile16_64<A_RC, B_RC, BX>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc16,
+                                              piece);
+        } else {
+            piece(0); piece(1); piece(2); piece(3);
+        }
+        advB();
+        advA();
+        sa = slot_of(2);
+    }
+
+#if C2_GEMM_DBG & 16
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_clk[0] = clock64() - clk0;
+        g_clk[1] = wall_clock64() - rt0;
+        g_clk[2] = wait_clk;
+        g_clk[3] = bar_clk;
+    }
+#endif
+    // ---- epilogue: C = alpha * acc + bias, transposed through LDS for 16-byte-per-lane stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+    asm volatile("" ::: "memory");
+    const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
+    float* C = a.C + (int64_t)split * a.slab_stride;
+    float* wl = reinterpret_cast<float*>(smem + wave * 8192);  // [32 rows][64 cols] fp32, private to the wave
+    const int col4 = n0 + wn * 64 + (lane & 15) * 4;
+    const bool vec_ok = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (col4 + 4 <= a.N);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (col4 + c < a.N) bv[c] = a.bias[col4 + c];
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {  // the wave's 64 rows in two quarters of 32: sixteen waves x 8 KB fit the LDS
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    wl[(ii * 16 + 4 * (lane >> 4) + e) * 64 + j * 16 + (lane & 15)] = acc16[qt * 2 + ii][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = rr * 4 + (lane >> 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
+            const int row = m0 + wm * 64 + qt * 32 + r;
+            if (row < a.M) {
+                float* dst = C + (int64_t)row * a.ldc + col4;
+                if (vec_ok) {
+                    f32x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = alpha * v[c] + bv[c];
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (col4 + c < a.N) dst[c] = alpha * v[c] + bv[c];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next quarter overwrites
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // bf16x3 on planes, fused: ONE pass over the reduction in which every K-tile brings its four operand tiles
 // (A_hi, B_hi, A_lo, B_lo; 16 KB each) and is multiplied three times (hi*hi + hi*lo + lo*hi) from the same
@@ -775,9 +1090,41 @@ int wide_tile(int dtype, const GemmArgs& a) {
     return 0;
 }
 
+// Which layouts run the sixteen-wave form of the 256x256 kernel.  Measured (tools/bench_gemm.py, same box): (XC, RC) -- the
+// decoder's weight gradient with its narrow operand transposed -- 207.6 -> 193.9 us; forward 216.4 -> 214.8 and 194.9 ->
+// 200.9, input gradient 216.3 -> 216.1, row-indexed (RC, XC) 214.5 -> 217.5: a wash.  So layout 3 only by default;
+// C2_WIDE_WAVES=16 / 8 puts every eligible layout / none on it (A/B).
+static bool wide16_on(int layout) {
+    static const int forced = []() { const char* e = getenv("C2_WIDE_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 16) return true;
+    if (forced == 8) return false;
+    return layout == 3;
+}
+template <bool A_RC, bool B_RC, int IDX>
+static void launch_w16(const GemmArgs& a, int nslab, hipStream_t stream) {
+    using namespace wide;
+    constexpr int LDS = 5 * 256 * BK * 2;
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_wide16_kernel<A_RC, B_RC, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_wide16_kernel<A_RC, B_RC, IDX>), dim3(tiles_m * tiles_n * nslab), dim3(1024), LDS, stream, a,
+                       tiles_m, tiles_n);
+}
+
 template <int NW>
 static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
     using namespace wide;
+    if constexpr (NW == 8) {
+        if (layout != 2 && wide16_on(layout)) {
+            if (layout == 0) launch_w16<true, true, 0>(a, nslab, stream);
+            else if (layout == 1) launch_w16<true, false, 0>(a, nslab, stream);
+            else launch_w16<false, true, 0>(a, nslab, stream);
+            return;
+        }
+    }
     constexpr int BX = 32 * NW;
     constexpr int LDS = (NW == 8 ? 5 : 9) * BX * BK * 2;
     const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;
@@ -809,6 +1156,11 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
 int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
     using namespace wide;
     if (!a.rows || a.A_lo || (layout != 0 && layout != 2 && layout != 4) || wide_tile(C2_BF16, a) != 256) return 3;
+    if (layout != 2 && wide16_on(layout)) {
+        if (layout == 0) launch_w16<true, true, 1>(a, nslab, stream);
+        else launch_w16<true, false, 2>(a, nslab, stream);
+        return 0;
+    }
     constexpr int NW = 8, BX = 256;
     constexpr int LDS = 5 * BX * BK * 2;
     const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;

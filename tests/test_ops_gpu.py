@@ -910,3 +910,45 @@ def test_weight_gradient_with_a_transposed_operand(M, N, K, nslab):
     assert torch.equal(e0, e1)
     with pytest.raises(ops.L.C2Error):  # a shape the 256x256 kernel does not take
         ops.linear_wgrad_bt(dl[:64, :128], dyt[:128, :64].contiguous(), torch.empty(128, 128, device=DEV))
+
+
+_W16_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from celligner2_amd import ops
+g = torch.Generator(device="cpu").manual_seed(11)
+M, N, K = 2104, 1024, 2312
+a = torch.randn(M + 7, K, generator=g).cuda().to(torch.bfloat16)
+w = torch.randn(N, K, generator=g).cuda().to(torch.bfloat16)
+dy = torch.randn(M, N, generator=g).cuda().to(torch.bfloat16)
+rows = torch.randint(0, M + 7, ((M + 63) // 64 * 64,), generator=g).to(torch.int32).cuda()
+out = {}
+out["fwd"] = ops.linear_fwd(a[:M], w, torch.empty(2, M, N, device="cuda"), nslab=2)
+out["fwd_rows"] = ops.linear_fwd_rows(a, rows, M, w, torch.empty(M, N, device="cuda"), bias=torch.ones(N, device="cuda"))
+out["dgrad"] = ops.linear_dgrad(dy, w, torch.empty(M, K, device="cuda"))
+dyt = ops.transpose_bf16(dy, torch.empty(N, M, device="cuda", dtype=torch.bfloat16))
+out["wgrad_rows_at"] = ops.linear_wgrad_rows_at(dyt, a, rows, torch.empty(N, K, device="cuda"))
+at = ops.transpose_bf16(a[:M].contiguous(), torch.empty(K, M, device="cuda", dtype=torch.bfloat16))
+out["wgrad_bt"] = ops.linear_wgrad_bt(dy, at, torch.empty(2, N, K, device="cuda"), nslab=2)
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[2])
+"""
+
+
+def test_sixteen_wave_form_of_the_gene_width_kernel_equals_the_eight_wave_form(tmp_path):
+    """The 256x256 kernel on sixteen waves of 64x64 (default for the (XC, RC) weight gradient only; C2_WIDE_WAVES=16 / 8 puts
+    every eligible layout / none on it, read once per process): same K-tile order, same MFMA -- bit-identical outputs for
+    the forward, row-indexed forward, input gradient and both transposed-operand weight gradients, ragged edges included."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for waves in ("8", "16"):
+        f = str(tmp_path / f"w{waves}.pt")
+        r = subprocess.run([sys.executable, "-c", _W16_SCRIPT, root, f], env=dict(os.environ, C2_WIDE_WAVES=waves),
+                           capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[waves] = torch.load(f, weights_only=True)
+    for k in res["8"]:
+        assert torch.equal(res["8"][k], res["16"][k]), k
+        assert torch.isfinite(res["8"][k]).all() and res["8"][k].abs().max() > 0
