@@ -1,0 +1,222 @@
+"""Random model shapes through the HIP step, each checked against the fp64 oracle (GPU box; test infrastructure).
+
+Widths, gene counts, latent sizes and batch sizes are drawn so that every dispatch rule of the engine is met from both
+sides: multiples and non-multiples of 4 / 8 / 64, widths on either side of the gene-width threshold, batches of a few rows
+and of a few hundred.  Per case: forward + backward of the four losses, one fused Adam step, a second forward -- losses,
+every gradient tensor and the losses after the update are compared with the oracle.  A refusal ("shape/alignment not
+taken"), a non-finite number or an error above the bound is printed as FAIL; the exit code is the number of failures.
+
+    python tools/fuzz_configs.py --cases 40 --seed 0 [--precision both]
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from celligner2_amd.model import Celligner2  # noqa: E402
+from celligner2_amd.optim import FusedAdam  # noqa: E402
+from oracle import c2_oracle as orc  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def draw_case(rng):
+    def width(lo, hi):
+        w = int(rng.integers(lo, hi))
+        k = rng.integers(0, 4)
+        return max(lo, (w // 64) * 64 if k == 0 else (w // 8) * 8 if k == 1 else (w // 4) * 4 if k == 2 else w)
+
+    G = width(40, 5200)
+    nh = int(rng.integers(2, 4))
+    hidden = [width(8, 1100 if i == 0 else 300) for i in range(nh)]
+    recon = ["nb", "nb", "mse", "zinb"][int(rng.integers(0, 4))]
+    # (fewer than two conditions: MSE only -- the reference's NB / ZINB dispersion is a linear map of a one-hot row that
+    # its encoder cannot build for one condition, and the oracle raises there as the reference does)
+    B = int(rng.choice([2, 7, 64, 128, 130, 257, 512, 700]))
+    use_mmd = bool(rng.integers(0, 2))
+    # (MMD on a latent space of a few dimensions: its sharpest kernels, exp(-5e5 d^2), make the gradient a discontinuous
+    # function of z in any finite precision -- seen at L = 2: 3e-3 in fp32 mode, tens of percent in bf16 mode)
+    L = int(rng.integers(8 if use_mmd else 2, 70))
+    return dict(G=G, hidden=hidden, L=L, C=int(rng.integers(0 if recon == "mse" else 2, 5)),
+                P=int(rng.choice([0, 3, 30, 65])), B=B, recon=recon,
+                use_mmd=use_mmd, mmd_on=["z", "y"][int(rng.integers(0, 2))],
+                # (use_bn on a batch of a few rows: statistics of two values, gradients ill-conditioned in any precision)
+                use_bn=bool(rng.integers(0, 5) == 0) and B >= 64, own_kl=bool(rng.integers(0, 4) == 0),
+                cls_hidden=[[32], [32, 64], [20]][int(rng.integers(0, 3))])
+
+
+VERBOSE = False
+
+
+def _shape_of_error(g, gr):
+    """Is an error rounding noise or structure?  `scale` = projection of the result on the oracle's gradient (noise leaves
+    it at 1), `rows` / `cols` = the largest share of the squared error held by one row / column, times their number
+    (noise: a few; a mishandled row, column or tile: hundreds)."""
+    d = g - gr
+    tot = float((d * d).sum())
+    if tot == 0 or g.ndim != 2 or min(g.shape) == 0:
+        return ""
+    scale = float((g * gr).sum() / max((gr * gr).sum(), 1e-300))
+    rows = float((d * d).sum(1).max() / tot * g.shape[0])
+    cols = float((d * d).sum(0).max() / tot * g.shape[1])
+    return f"  [scale {scale:.4f}, rows x{rows:.1f}, cols x{cols:.1f}]"
+
+
+def run_case(c, precision, seed):
+    rng = np.random.default_rng(seed)
+    G, L, C, P, B = c["G"], c["L"], c["C"], c["P"], c["B"]
+    use_mmd = c["use_mmd"] and C > 1
+    cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=c["hidden"], latent_dim=L, n_conditions=C, n_predictors=P,
+                  classifier_hidden_layer_sizes=c["cls_hidden"], recon_loss=c["recon"], use_own_kl=c["own_kl"],
+                  use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0, use_bn=c["use_bn"])
+    params = orc.init_params(cfg, seed, np.float32)
+    buffers = {}
+    for k, shp in orc.buffer_shapes(cfg).items():
+        buffers[k] = (np.zeros(shp, np.int64) if k.endswith("tracked") else
+                      (1 + 0.2 * rng.uniform(size=shp) if k.endswith("var") else 0.1 * rng.standard_normal(shp))
+                      .astype(np.float32))
+    depth = rng.uniform(0.5, 2.0, (B, 1))
+    prof = np.exp(rng.normal(0.5, 1.2, (1, G)))
+    x = rng.poisson(depth * prof).astype(np.float32)
+    if c["recon"] == "mse":
+        x = np.log1p(x)
+    cond = np.zeros((B, max(C, 0)), np.int64)
+    if C:
+        cond[np.arange(B), rng.integers(0, C, B)] = 1
+        if C > 2:
+            cond[rng.uniform(size=B) < 0.3, C - 1] = 1  # multi-hot rows
+    batch = dict(x=x, batch=cond, sizefactor=np.maximum(x.sum(1), 1.0).astype(np.float32),
+                 goodloc=rng.uniform(size=(B, G)) > 0.01)
+    if P:
+        cls = np.zeros((B, P), np.int64)
+        cls[np.arange(B), rng.integers(0, P, B)] = 1
+        cls[rng.uniform(size=B) < 0.2] = -1
+        batch["classes"] = cls
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    alpha = 1e-3
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    obatch = dict(batch)
+    if P:
+        obatch["classes"] = batch["classes"].copy()
+    else:
+        obatch["classes"] = None
+    ref = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), buffers=buffers)
+    state = {}
+    orc.adam_step(p64, ref["grads"], state, lr=1e-3, eps=0.01, weight_decay=0.04)
+    if P:
+        obatch["classes"] = batch["classes"].copy()
+    ref2 = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), want_grads=False,
+                                buffers=ref.get("buffers", buffers))
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = Celligner2(G, c["hidden"], L, 0.0, c["own_kl"], c["recon"], c["use_bn"],
+                       conditions=[f"c{i}" for i in range(C)], use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0,
+                       predictors=[f"p{i}" for i in range(P)], classifier_hidden_layer_sizes=c["cls_hidden"],
+                       precision=precision)
+    m.load_state_dict({k: torch.tensor(v) for k, v in {**params, **buffers}.items()})
+    m.to(DEV).train()
+    m._forced_noise = dict(eps=torch.tensor(eps).to(DEV), masks={})
+    tb = {k: torch.tensor(v).to(DEV) for k, v in batch.items()}
+
+    def fwd():
+        b = dict(tb)
+        if P:
+            b["classes"] = tb["classes"].clone()
+        return m(**b)
+
+    lookup, updated = m._adam_hooks()
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3, eps=0.01, weight_decay=0.04,
+                    shadow_lookup=lookup, on_updated=updated)
+    r, k, mm, ce = fwd()
+    (r + alpha * k + mm + ce).backward()
+    m._engine().check_status()
+    got = [float(r), float(k), float(mm), float(ce)]
+    # A unit whose normalised pre-activation is within rounding of zero can come out on the other side of the ReLU than
+    # in the fp64 oracle (seen: -1.1e-7 against +9.6e-8): that row's gradient then differs by one unit's worth, ~1/B of a
+    # gradient tensor.  Counted here (fp32 mode, where the normalised activations agree to 1e-6) and allowed for below.
+    flips = 0
+    if precision == "fp32":
+        for blk, cache in ref["caches"].items():
+            ye = m._engine()._ws.get(blk + ".yhat")
+            if ye is not None and tuple(ye.shape) == cache["pre"].shape:
+                flips += int(((ye.double().cpu().numpy() > 0) != (cache["pre"] > 0)).sum())
+    tol_l = 1e-4 if precision == "fp32" else 1e-2
+    # bf16 mode: the bound of the parity tests (1e-2 at the shapes pinned there) does not hold for every shape -- a
+    # LayerNorm over a handful of features or a batch of a few rows leaves little averaging of the operands' 2^-9 rounding.
+    # The sweep looks for refusals, non-finite numbers and STRUCTURED errors; rounding noise passes with a note (--verbose), errors of 30 % and more do not.
+    tol_g = (2e-3 if not flips else 3e-2) if precision == "fp32" else (0.3 if B >= 16 else 0.5)
+    bad = []
+    for i in range(4):
+        if not abs(got[i] - ref["losses"][i]) <= tol_l * max(abs(ref["losses"][i]), 1.0):
+            bad.append(f"loss{i} {got[i]:.6g} vs {ref['losses'][i]:.6g}")
+    worst = (0.0, "")
+    for n, p in m.named_parameters():
+        gr = ref["grads"].get(n)
+        if gr is None or p.grad is None:
+            if (gr is None) != (p.grad is None) and gr is not None and np.abs(gr).max() > 0:
+                bad.append(f"grad presence {n}")
+            continue
+        g = p.grad.double().cpu().numpy()
+        den = np.linalg.norm(gr)
+        if n.endswith(".bias") and n[:-4] + "weight" in ref["grads"]:
+            den = max(den, np.linalg.norm(ref["grads"][n[:-4] + "weight"]))
+        e = float(np.linalg.norm(g - gr) / max(den, 1e-30)) if den > 1e-12 else float(np.abs(g).max())
+        if not np.isfinite(e) or e > tol_g:
+            bad.append(f"grad {n} {e:.3g}" + _shape_of_error(g, gr))
+        elif e > 1e-2 and VERBOSE:
+            print(f"      note: {n} {e:.3g}" + _shape_of_error(g, gr))
+        worst = max(worst, (e, n))
+    opt.step()
+    with torch.no_grad():
+        r2 = fwd()
+    m._engine().check_status()
+    got2 = [float(v) for v in r2]
+    for i in range(4):
+        # (bf16 mode on a batch of a few rows: the update of step 1 is lr * g / (|g| + eps), which turns the rounding noise
+        # of small gradient entries into O(lr) differences of the parameters -- the KL term shows it first)
+        tol2 = 1e-3 if precision == "fp32" else (0.1 if B >= 16 else 0.25)
+        if not abs(got2[i] - ref2["losses"][i]) <= tol2 * max(abs(ref2["losses"][i]), 1.0):
+            bad.append(f"loss{i} after Adam {got2[i]:.6g} vs {ref2['losses'][i]:.6g}")
+    if flips and VERBOSE:
+        print(f"      note: {flips} unit(s) on the other side of a ReLU than in the oracle")
+    return bad, worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", default="both")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    global VERBOSE
+    VERBOSE = a.verbose
+    rng = np.random.default_rng(a.seed)
+    fails = 0
+    for i in range(a.cases):
+        c = draw_case(rng)
+        for prec in (("fp32", "bf16") if a.precision == "both" else (a.precision,)):
+            t0 = time.time()
+            try:
+                bad, worst = run_case(c, prec, a.seed * 1000 + i)
+            except Exception as e:  # a refusal or a kernel error is a finding, not the end of the sweep
+                bad, worst = [f"{type(e).__name__}: {e}"], (float("nan"), "")
+                traceback.print_exc()
+            fails += bool(bad)
+            print(f"[{i:3d}] {prec} {'FAIL' if bad else 'ok  '} {c} worst grad {worst[0]:.2e} {worst[1]} "
+                  f"({time.time() - t0:.1f}s)" + ("".join("\n      " + b for b in bad)), flush=True)
+    print(f"{fails} failure(s)")
+    sys.exit(min(fails, 100))
+
+
+if __name__ == "__main__":
+    main()
