@@ -49,7 +49,9 @@ def draw_case(rng):
                 use_mmd=use_mmd, mmd_on=["z", "y"][int(rng.integers(0, 2))],
                 # (use_bn on a batch of a few rows: statistics of two values, gradients ill-conditioned in any precision)
                 use_bn=bool(rng.integers(0, 5) == 0) and B >= 64, own_kl=bool(rng.integers(0, 4) == 0),
-                cls_hidden=[[32], [32, 64], [20]][int(rng.integers(0, 3))])
+                cls_hidden=[[32], [32, 64], [20]][int(rng.integers(0, 3))],
+                # the surgery regime (SurgeryMixin.load_query_data, freeze=True): only the condition weights train
+                freeze=bool(rng.integers(0, 4) == 0))
 
 
 VERBOSE = False
@@ -109,7 +111,9 @@ def run_case(c, precision, seed):
         obatch["classes"] = None
     ref = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), buffers=buffers)
     state = {}
-    orc.adam_step(p64, ref["grads"], state, lr=1e-3, eps=0.01, weight_decay=0.04)
+    frozen = c.get("freeze", False) and C > 0
+    trainable = [k for k in params if (not frozen or "cond_L" in k or k == "theta")]
+    orc.adam_step(p64, ref["grads"], state, lr=1e-3, eps=0.01, weight_decay=0.04, names=trainable)
     if P:
         obatch["classes"] = batch["classes"].copy()
     ref2 = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), want_grads=False,
@@ -124,6 +128,8 @@ def run_case(c, precision, seed):
                        precision=precision)
     m.load_state_dict({k: torch.tensor(v) for k, v in {**params, **buffers}.items()})
     m.to(DEV).train()
+    for n, p in m.named_parameters():
+        p.requires_grad_(n in trainable)
     m._forced_noise = dict(eps=torch.tensor(eps).to(DEV), masks={})
     tb = {k: torch.tensor(v).to(DEV) for k, v in batch.items()}
 
@@ -160,7 +166,9 @@ def run_case(c, precision, seed):
             bad.append(f"loss{i} {got[i]:.6g} vs {ref['losses'][i]:.6g}")
     worst = (0.0, "")
     for n, p in m.named_parameters():
-        gr = ref["grads"].get(n)
+        gr = ref["grads"].get(n) if n in trainable else None
+        if n not in trainable and p.grad is not None:
+            bad.append(f"frozen {n} has a gradient")
         if gr is None or p.grad is None:
             if (gr is None) != (p.grad is None) and gr is not None and np.abs(gr).max() > 0:
                 bad.append(f"grad presence {n}")

@@ -1,0 +1,116 @@
+"""Random model shapes through the TRAINER (GPU box; test infrastructure): the captured-graph loop against the loop
+launched kernel by kernel, which must agree bit for bit -- parameters, optimizer-visible state and logs -- over two
+epochs with a short last batch and a validation pass per epoch.  Shapes come from fuzz_configs.draw_case.
+
+    python tools/fuzz_trainer.py --cases 20 --seed 0
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import fuzz_configs as fz  # noqa: E402
+from celligner2_amd.dataset import DeviceDataset  # noqa: E402
+from celligner2_amd.model import Celligner2  # noqa: E402
+from celligner2_amd.trainer import Celligner2Trainer  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _data(c, n, seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    G, C, P = c["G"], c["C"], c["P"]
+    gene = torch.exp(torch.randn(1, G, device=DEV, generator=g) * 1.2 + 0.5)
+    depth = torch.empty(n, 1, device=DEV).uniform_(0.5, 2.0, generator=g)
+    X = torch.poisson(depth * gene, generator=g)
+    if c["recon"] == "mse":
+        X = torch.log1p(X)
+    good = torch.rand(n, G, device=DEV, generator=g) > 0.01
+    cond = torch.zeros(n, C, dtype=torch.int64, device=DEV)
+    if C:
+        cond[torch.arange(n, device=DEV), torch.randint(0, C, (n,), device=DEV, generator=g)] = 1
+    cls = None
+    if P:
+        cls = torch.zeros(n, P, dtype=torch.int64, device=DEV)
+        lab = torch.randint(0, P + 2, (n,), device=DEV, generator=g)
+        known = lab < P
+        cls[torch.arange(n, device=DEV)[known], lab[known]] = 1
+        cls[~known] = -1
+    return DeviceDataset.from_tensors(X, X.sum(1).clamp_min(1.0), good, cond if C else None, cls)
+
+
+def run_case(c, precision, seed):
+    B = max(c["B"], 32)
+    rng = np.random.default_rng(seed)
+    n_train = int(rng.integers(3, 6)) * B + int(rng.integers(1, B))
+    n_valid = int(rng.integers(1, 3)) * B + int(rng.integers(0, B))
+    use_mmd = c["use_mmd"] and c["C"] > 1
+    out = []
+    for graph in (False, True):
+        torch.manual_seed(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = Celligner2(c["G"], c["hidden"], c["L"], 0.05, c["own_kl"], c["recon"], c["use_bn"],
+                               conditions=[f"c{i}" for i in range(c["C"])], use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0,
+                               predictors=[f"p{i}" for i in range(c["P"])], classifier_hidden_layer_sizes=c["cls_hidden"],
+                               precision=precision).to(DEV).train()
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        tr = Celligner2Trainer(model, None, train_data=_data(c, n_train, seed), valid_data=_data(c, n_valid, seed + 1),
+                               batch_size=B, use_leiden=False, alpha_kl=1e-3, alpha_iter_anneal=10, monitor=False,
+                               use_early_stopping=False, rng="device", seed=5, graph=graph,
+                               # (nothing to stratify by: the weights would be all zero, which the sampler refuses as
+                               # torch's WeightedRandomSampler does)
+                               use_stratified_sampling=bool(c["C"] or c["P"]))
+        tr.train(n_epochs=2, lr=1e-3)
+        out.append(({k: v.clone() for k, v in model.state_dict().items()}, dict(tr.logs)))
+        moved = sum(not torch.equal(init[k], v) for k, v in model.state_dict().items())
+        assert moved >= 8 and len(tr.logs["epoch_loss"]) == 2 and "val_loss" in tr.logs, \
+            (moved, list(tr.logs))
+    (s0, l0), (s1, l1) = out
+    bad = []
+    for k in s0:
+        if not torch.equal(s0[k], s1[k]):
+            bad.append(f"state {k}: {(s0[k].double() - s1[k].double()).abs().max().item():.3e}")
+    for k in l0:
+        if not np.allclose(l0[k], l1[k], rtol=1e-6):
+            bad.append(f"log {k}: {l0[k]} vs {l1[k]}")
+        if not np.isfinite(np.asarray(l1[k], dtype=np.float64)).all():
+            bad.append(f"log {k} not finite: {l1[k]}")
+    return bad, (n_train, n_valid, B)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed + 100)
+    fails = 0
+    for i in range(a.cases):
+        c = fz.draw_case(rng)
+        for prec in ("fp32", "bf16"):
+            t0 = time.time()
+            try:
+                bad, sizes = run_case(c, prec, a.seed * 1000 + i)
+            except Exception as e:
+                bad, sizes = [f"{type(e).__name__}: {e}"], None
+                traceback.print_exc()
+            fails += bool(bad)
+            print(f"[{i:3d}] {prec} {'FAIL' if bad else 'ok  '} {c} rows/valid/batch {sizes} ({time.time() - t0:.1f}s)"
+                  + "".join("\n      " + b for b in bad[:8]), flush=True)
+    print(f"{fails} failure(s)")
+    sys.exit(min(fails, 100))
+
+
+if __name__ == "__main__":
+    main()
