@@ -38,8 +38,12 @@ def main():
     shard = variant.startswith("shard")
     precision = "bf16" if variant.endswith("bf16") else "fp32"
     global NSTEPS
-    NSTEPS = 6
+    NSTEPS = int(os.environ.get("C2_DDP_STEPS", "6"))
+    GSTEP = int(os.environ.get("C2_DDP_GSTEP", "0"))  # (debugging: the step whose losses / gradients are compared)
     G, hidden, L, C, P, B = (2304 if precision == "bf16" else 256), [48, 24], 8, 3, 4, 64
+    if os.environ.get("C2_DDP_SHAPE"):  # tools/fuzz_ddp.py: "G,L,B,h1,h2[,h3]" -- odd widths through the bucket / chunk bookkeeping
+        v = [int(t) for t in os.environ["C2_DDP_SHAPE"].split(",")]
+        G, L, B, hidden = v[0], v[1], v[2], v[3:]
     cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=hidden, latent_dim=L, n_conditions=C, n_predictors=P,
                   recon_loss="nb", use_mmd=True, beta=20.0, use_bn=use_bn)
     rng = np.random.default_rng(0)
@@ -69,9 +73,13 @@ def main():
         first = None
         for step in range(NSTEPS):  # several steps back to back, nothing synchronised in between
             opt.zero_grad()
+            if os.environ.get("C2_DDP_FORCE_REFRESH") in ("both", "ddp" if sync is not None else "ref") and step:
+                eng = m._engine()  # (debugging: drop every operand copy of the weights before the forward)
+                eng._shadow_ver = {k_: None for k_ in eng._shadow_ver}
+                eng._wplanes.clear()
             r, k, mm, ce = m(**{k_: torch.tensor(v[sl]).cuda() for k_, v in full.items()})
             (r + 1e-3 * k + mm + ce).backward()
-            if step == 0:  # losses / gradients of the first step are compared; parameters after the last
+            if step == GSTEP:  # losses / gradients of the first step are compared; parameters after the last
                 first = (torch.stack([r, k, mm, ce]).detach().clone(),
                          {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
             opt.step()
@@ -96,6 +104,21 @@ def main():
         assert all(lo_ <= p.data_ptr() < hi_ for p in m.parameters()), "parameters are views of the flat buffer"
         assert all((hi - lo) % (64 * world) == 0 for lo, hi in eng.buckets)
     m._engine().check_status()
+    if os.environ.get("C2_DDP_DUMP") and rank == 0:  # (debugging: the workspaces of the last backward, rank 0's rows)
+        we, wr = m._engine()._ws, ref_m._engine()._ws
+        for key in sorted(we, key=str):
+            a, b = we[key], wr.get(key)
+            if not (torch.is_tensor(a) and torch.is_tensor(b) and a.is_floating_point()):
+                continue
+            if a.dim() == 3 and b.dim() == 3 and a.shape[1] == per and b.shape[1] == B:
+                a, b = a.float().sum(0), b.float().sum(0)[:per]
+            elif a.dim() == 2 and b.dim() == 2 and a.shape[0] == per and b.shape[0] == B and a.shape[1] == b.shape[1]:
+                a, b = a.float(), b.float()[:per]
+            else:
+                continue
+            e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+            flips = int(((a > 0) != (b > 0)).sum()) if str(key).endswith("yhat") else -1
+            print(f"   ws {key}: {tuple(a.shape)} {e:.3g}" + (f"  sign disagreements {flips}" if flips >= 0 else ""))
     ok = True
     if rank == 0:
         tol_g, tol_p = (2e-2, 1e-4) if precision == "bf16" else (1e-4, 1e-5)  # bf16: operand copies may round apart
@@ -110,15 +133,26 @@ def main():
             if use_bn and n.endswith(".bias") and n[:-4] + "weight" in ref_g:  # cancelling batch sums (gu.grad_err)
                 den = max(den, ref_g[n[:-4] + "weight"].abs().max().item())
             err = (grads[n] - ref_g[n]).abs().max().item() / max(den, 1e-30)
+            worst_g = max(locals().get("worst_g", 0.0), err)
+            if os.environ.get("C2_DDP_VERBOSE"):
+                print(f"   grad {n}: {err:.3g}")
             if err > tol_g:
                 ok = False
                 print("MISMATCH", n, err)
         for n, p in ref_m.named_parameters():  # parameters after the optimizer step
-            err = (dict(m.named_parameters())[n].detach() - p.detach()).abs().max().item() / max(p.abs().max().item(), 1e-30)
-            if err > tol_p:
+            dabs = (dict(m.named_parameters())[n].detach() - p.detach()).abs().max().item()
+            err = dabs / max(p.abs().max().item(), 1e-30)
+            # (second bound, in units of the step: Adam divides every entry by its own |g| + eps, so an entry with
+            # |g| << eps = 0.01 turns a summation-order difference d of the gradient into lr * d / eps -- with gradients
+            # up to ~100 and d ~ 2.5e-7 of that, 0.25 % of lr per step, seen at 8 ranks x 2502 genes.  A chunk that is
+            # skipped or updated twice moves by ~lr per step, 50x this bound.)
+            # (tools/fuzz_ddp.py widens it to 0.15 lr per step: one unit of one row on the other side of a ReLU than in
+            # the single-process run -- their kernels differ by ~1e-6 in bf16x3 mode, counted with C2_DDP_DUMP=1 -- changes
+            # that row's gradient, ~1/B of every tensor upstream, and has been seen to move small-|g| entries by 0.06 lr)
+            if err > tol_p and dabs > float(os.environ.get("C2_DDP_PARAM_TOL_LR", "2e-2")) * 1e-3 * NSTEPS:
                 ok = False
                 print("MISMATCH param after Adam", n, err)
-        print("losses ddp", losses, "single", ref_l)
+        print("losses ddp", losses, "single", ref_l, "worst first-step gradient error", locals().get("worst_g"))
     flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

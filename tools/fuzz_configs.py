@@ -13,6 +13,7 @@ import os
 import sys
 import time
 import traceback
+import warnings
 
 import numpy as np
 import torch
@@ -39,7 +40,7 @@ def draw_case(rng):
     recon = ["nb", "nb", "mse", "zinb"][int(rng.integers(0, 4))]
     # (fewer than two conditions: MSE only -- the reference's NB / ZINB dispersion is a linear map of a one-hot row that
     # its encoder cannot build for one condition, and the oracle raises there as the reference does)
-    B = int(rng.choice([2, 7, 64, 128, 130, 257, 512, 700]))
+    B = int(rng.choice([2, 7, 24, 38, 64, 128, 130, 257, 512, 700]))
     use_mmd = bool(rng.integers(0, 2))
     # (MMD on a latent space of a few dimensions: its sharpest kernels, exp(-5e5 d^2), make the gradient a discontinuous
     # function of z in any finite precision -- seen at L = 2: 3e-3 in fp32 mode, tens of percent in bf16 mode)
@@ -119,7 +120,6 @@ def run_case(c, precision, seed):
     ref2 = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), want_grads=False,
                                 buffers=ref.get("buffers", buffers))
 
-    import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = Celligner2(G, c["hidden"], L, 0.0, c["own_kl"], c["recon"], c["use_bn"],
@@ -184,6 +184,7 @@ def run_case(c, precision, seed):
             print(f"      note: {n} {e:.3g}" + _shape_of_error(g, gr))
         worst = max(worst, (e, n))
     opt.step()
+    bn_before = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
     with torch.no_grad():
         r2 = fwd()
     m._engine().check_status()
@@ -194,6 +195,39 @@ def run_case(c, precision, seed):
         tol2 = 1e-3 if precision == "fp32" else (0.1 if B >= 16 else 0.25)
         if not abs(got2[i] - ref2["losses"][i]) <= tol2 * max(abs(ref2["losses"][i]), 1.0):
             bad.append(f"loss{i} after Adam {got2[i]:.6g} vs {ref2['losses'][i]:.6g}")
+    # Every operand copy the engine keeps of a weight (bf16 shadows, padded shadows, (hi, lo) planes, transposes) must
+    # follow the optimizer: a second step and a forward on a FRESH module built from the updated state_dict -- which
+    # has no copies yet -- must give the same bits.
+    opt.zero_grad()
+    r3 = fwd()
+    (r3[0] + alpha * r3[1] + r3[2] + r3[3]).backward()
+    g3 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2 = Celligner2(G, c["hidden"], L, 0.0, c["own_kl"], c["recon"], c["use_bn"],
+                        conditions=[f"c{i}" for i in range(C)], use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0,
+                        predictors=[f"p{i}" for i in range(P)], classifier_hidden_layer_sizes=c["cls_hidden"],
+                        precision=precision)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    if c["use_bn"]:  # the fresh module repeats the tracked forward from the statistics the first one started from
+        sd.update({k: v.clone() for k, v in bn_before.items()})
+    m2.load_state_dict(sd)
+    m2.to(DEV).train()
+    for n, p in m2.named_parameters():
+        p.requires_grad_(n in trainable)
+    m2._forced_noise = m._forced_noise
+    b = dict(tb)
+    if P:
+        b["classes"] = tb["classes"].clone()
+    r4 = m2(**b)
+    (r4[0] + alpha * r4[1] + r4[2] + r4[3]).backward()
+    for i in range(4):
+        if not torch.equal(r3[i], r4[i]):
+            bad.append(f"loss{i} of step 2: {float(r3[i])!r} with the engine's operand copies, {float(r4[i])!r} on a fresh module")
+    for n, p in m2.named_parameters():
+        if p.grad is not None and not torch.equal(p.grad, g3[n]):
+            e = float((p.grad - g3[n]).norm() / p.grad.norm().clamp_min(1e-30))
+            bad.append(f"gradient {n} of step 2 differs from a fresh module's by {e:.3g}")
     if flips and VERBOSE:
         print(f"      note: {flips} unit(s) on the other side of a ReLU than in the oracle")
     return bad, worst
