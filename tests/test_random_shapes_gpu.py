@@ -2,7 +2,8 @@
 draws gene counts, widths, latent sizes and batches on both sides of every dispatch rule of the engine -- multiples
 and non-multiples of 4 / 8 / 64, gene-width and narrow layers, batches of 2 to 700 rows, NB / ZINB / MSE, MMD on z or y,
 LayerNorm / BatchNorm, with and without conditions and predictors).  Per case: the four losses, every gradient tensor,
-and the losses after one fused Adam step.  fp32 mode: 1e-4 on losses, 2e-3 on gradients (3e-2 for a case in which a
+the losses after one fused Adam step, bit-equality of the next step with a fresh module built from the updated
+state_dict (no stale operand copies), and the inference path (get_latent / reconstructLatent) in eval mode.  fp32 mode: 1e-4 on losses, 2e-3 on gradients (3e-2 for a case in which a
 unit sits on the other side of a ReLU than in the oracle, which the tool counts); bf16 mode: 1e-2 on losses and a loose
 bound on gradients (30 %: the sweep looks for refusals, non-finite values and structured errors there -- the 1e-2 parity
 bound of bf16 mode is test_step_gpu.py's, at the pinned realistic shapes; narrow LayerNorms and batches of a few rows

@@ -228,6 +228,40 @@ def run_case(c, precision, seed):
         if p.grad is not None and not torch.equal(p.grad, g3[n]):
             e = float((p.grad - g3[n]).norm() / p.grad.norm().clamp_min(1e-30))
             bad.append(f"gradient {n} of step 2 differs from a fresh module's by {e:.3g}")
+    # The inference path (Celligner2.get_latent / reconstructLatent, celligner2.py:376-420) on the updated module, in eval
+    # mode (running statistics under use_bn), against the oracle's forward at the same parameters with eps = 0 (z = mu).
+    m2.eval()
+    xt, ct = tb["x"], (tb["batch"] if C else None)
+    mu_e, cl_e = m2.get_latent(xt, ct, mean=True, add_classpred=bool(P))
+    z_e, _ = m2.get_latent(xt, ct, mean=False)
+    rec = m2.reconstructLatent(mu_e, ct)
+    p_now = {k_: v.detach().double().cpu().numpy() for k_, v in m2.named_parameters()}
+    buf_now = {k_: v.cpu().numpy() for k_, v in m2.named_buffers()}
+    ob = dict(obatch)
+    if P:
+        ob["classes"] = batch["classes"].copy()
+    if c["recon"] == "mse":  # the reference's get_latent takes log(1 + x) for EVERY recon loss (celligner2.py:398-399),
+        ob["x"] = np.log1p(batch["x"])  # its forward only for NB / ZINB (:269-274): the oracle's forward is given that input
+    ev = orc.forward_backward(p_now, cfg, ob, np.zeros((B, L)), want_grads=False, train=False, buffers=buf_now)
+    tol_i = 1e-4 if precision == "fp32" else 3e-2
+
+    def close(name, got_t, want):
+        got_n = got_t.double().cpu().numpy()
+        e = float(np.abs(got_n - want).max() / max(np.abs(want).max(), 1e-30))
+        if not e <= tol_i:
+            bad.append(f"inference {name}: {e:.3g}")
+
+    close("z_mean", mu_e, ev["mu"])
+    close("z", z_e, ev["mu"] + np.sqrt(np.exp(ev["lv"]) + 1e-4) * eps.astype(np.float64))
+    if P:
+        close("class logits on z_mean", cl_e, ev["class_logits"])
+    o = ev["logits"]
+    if c["recon"] == "mse":
+        close("reconstruction", rec[0], np.maximum(o, 0))
+    else:
+        so = np.exp(o - o.max(1, keepdims=True))
+        close("reconstruction", rec[0], so / so.sum(1, keepdims=True))
+    close("y1", rec[-1], ev["y1"])
     if flips and VERBOSE:
         print(f"      note: {flips} unit(s) on the other side of a ReLU than in the oracle")
     return bad, worst
