@@ -52,7 +52,8 @@ def draw_case(rng):
                 use_bn=bool(rng.integers(0, 5) == 0) and B >= 64, own_kl=bool(rng.integers(0, 4) == 0),
                 cls_hidden=[[32], [32, 64], [20]][int(rng.integers(0, 3))],
                 # the surgery regime (SurgeryMixin.load_query_data, freeze=True): only the condition weights train
-                freeze=bool(rng.integers(0, 4) == 0))
+                # (2: freeze_expression=False -- the dispersion, every first layer and its norm train, _base.py:342-354)
+                freeze=int(rng.choice([0, 0, 1, 2])))
 
 
 VERBOSE = False
@@ -112,8 +113,9 @@ def run_case(c, precision, seed):
         obatch["classes"] = None
     ref = orc.forward_backward(p64, cfg, obatch, eps.astype(np.float64), gscale=(1, alpha, 1, 1), buffers=buffers)
     state = {}
-    frozen = c.get("freeze", False) and C > 0
-    trainable = [k for k in params if (not frozen or "cond_L" in k or k == "theta")]
+    frozen = int(c.get("freeze", 0)) if C > 0 else 0
+    keep = {0: ("",), 1: ("theta", "cond_L.weight"), 2: ("theta", "L0", "N0")}[frozen]
+    trainable = [k for k in params if any(f in k for f in keep)]
     orc.adam_step(p64, ref["grads"], state, lr=1e-3, eps=0.01, weight_decay=0.04, names=trainable)
     if P:
         obatch["classes"] = batch["classes"].copy()
