@@ -476,7 +476,7 @@ class StepEngine:
             g = self.gbuf(name)
         N, K = g.shape
         if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): gene-width by construction
-            dy = self._narrow_t(dy, "dyt", N, K)  # (the narrow operand transposed: see _narrow_t)
+            dy = self._narrow_t(dy, "dyt", N, K, a[0])  # (the narrow operand transposed: see _narrow_t)
             if not self._wgrad_two_part(dy, a, g, alpha):
                 ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
                 if ns == 1:
@@ -488,7 +488,7 @@ class StepEngine:
             return
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
         if not pl:
-            at = self._narrow_t(a, "at", N, K)
+            at = self._narrow_t(a, "at", N, K, dy)
             if self._wgrad_two_part(dy, at, g, alpha):
                 return
             if isinstance(at, _T):
@@ -508,13 +508,17 @@ class StepEngine:
             ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
             ops.sum_slabs(slabs, g)
 
-    def _narrow_t(self, t, key, N, K):
+    def _narrow_t(self, t, key, N, K, other):
         """A gene-width bf16 weight gradient [N, K] reduced over the batch multiplies faster when its NARROW operand
         ([B, H]: 8 MB at 4096 x 1024) is handed over transposed -- the cells contiguous, read row-wise, 16x16x32 MFMA -- than
         with both operands through the transposing LDS read (c2_linear_wgrad_bt / _rows_at; same result bit for bit).
-        Returns the transposed copy wrapped in _T when the 256x256 kernel takes the shape, else `t` unchanged."""
+        Returns the transposed copy wrapped in _T when the 256x256 kernel takes the shape, else `t` unchanged.
+        `other`: the gene-width operand -- those entry points refuse what the LDS-DMA kernel cannot read (rows that do not
+        start on 16 bytes: a gene count that is not a multiple of 8), where c2_linear_wgrad falls back to the
+        register-staged kernel by itself; so such operands stay on it."""
         B, H = t.shape
         if not (t.dtype == torch.bfloat16 and B % 8 == 0 and B >= 1024 and H <= 2048 and max(N, K) >= self.WIDE
+                and other.dtype == torch.bfloat16 and other.stride(0) % 8 == 0 and other.data_ptr() % 16 == 0
                 and ops.gemm_tile(t.dtype, N, K, B, self.x3) == 256):
             return t
         return _T(ops.transpose_bf16(t, self.buf(f"wgrad.{key}.{H}x{B}", (H, B), torch.bfloat16)))

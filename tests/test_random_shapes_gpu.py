@@ -34,3 +34,16 @@ def test_random_shapes_match_the_oracle(seed):
             if bad:
                 failures.append((i, prec, c, bad))
     assert not failures, failures
+
+
+def test_gene_count_not_a_multiple_of_8_at_a_large_batch():
+    """Found by tools/fuzz_trainer.py --big (17 948 genes, batch 4096, bf16 mode): the decoder's weight gradient took the
+    transposed-narrow-operand entry point (c2_linear_wgrad_bt), which refuses a gene-width operand whose rows do not start
+    on 16 bytes, instead of c2_linear_wgrad, which falls back by itself.  Smallest shape that reaches that dispatch."""
+    fz = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(fz)
+    c = dict(G=2052, hidden=[1024, 64], L=10, C=2, P=0, B=1024, recon="nb", use_mmd=False, mmd_on="z", use_bn=False,
+             own_kl=False, cls_hidden=[32], freeze=0)
+    for prec in ("fp32", "bf16"):
+        bad, _ = fz.run_case(c, prec, 5)
+        assert not bad, (prec, bad)
