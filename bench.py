@@ -45,6 +45,11 @@ CONFIGS = {
                desc="pancreas shape 15.7k x 1000, hidden [128,128], latent 10, MSE on log1p counts + MMD, 5 conditions"),
     "c3": dict(G=19000, hidden=[820, 512, 256], latent=26, C=3, P=30, cls_hidden=[32, 64], B=4096, N=30000, beta=1.0,
                desc="GTEx+TCGA+CCLE shape 30k x 19k, hidden [820,512,256], latent 26, NB + MMD + classifier, 3 conditions"),
+    # gene counts that are not multiples of 8 (rows of the [B, G] operands do not start on 16 bytes unless padded)
+    "c4g4": dict(G=19004, hidden=[1024, 512], latent=64, C=3, P=0, cls_hidden=[32], B=4096, N=100000, beta=1.0,
+                 desc="c4 with 19 004 genes (a multiple of 4, not of 8)"),
+    "c4g1": dict(G=19001, hidden=[1024, 512], latent=64, C=3, P=0, cls_hidden=[32], B=4096, N=100000, beta=1.0,
+                 desc="c4 with 19 001 genes (odd)"),
     "c5": dict(G=19000, hidden=[256, 128], latent=16, C=3, P=30, cls_hidden=[32, 64], B=128, N=1000, beta=500.0,
                dr=0.0, surgery=True,
                desc="surgery fine-tune: the c2 model with a third condition, 1000 query rows, freeze + freeze_expression "

@@ -154,7 +154,8 @@ class DeviceDataset:
         cache = self.__dict__.setdefault("_xin_res", {})
         t = cache.get(bool(apply_log))
         if t is None:
-            t = torch.empty((self.n, self.G), dtype=torch.bfloat16, device=self.device)
+            # (rows start on 16 bytes for the LDS-DMA GEMMs: a gene count that is not a multiple of 8 gets zero pad columns)
+            t = torch.zeros((self.n, (self.G + 7) // 8 * 8), dtype=torch.bfloat16, device=self.device)[:, :self.G]
             for s in range(0, self.n, 16384):
                 ops.prep_input(self.data[s:s + 16384], t[s:s + 16384], bool(apply_log))
             cache[bool(apply_log)] = t
@@ -198,7 +199,14 @@ class DeviceDataset:
             out["xin_full"] = self.xin_resident(apply_log)
             idx32 = out["row_index32"] = get("row_index32", ((n + 63) // 64 * 64,), torch.int32)
         elif xin_dtype is not None:
-            xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
+            if xin_dtype == torch.bfloat16 and self.G % 8:  # (see xin_resident)
+                g8 = (self.G + 7) // 8 * 8
+                full = bufs.get("xin.padded")
+                if full is None or tuple(full.shape) != (n, g8):
+                    full = bufs["xin.padded"] = torch.zeros((n, g8), dtype=xin_dtype, device=self.device)
+                xin = out["xin"] = full[:, :self.G]
+            else:
+                xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
         rc = rc_o = None
         if nb_const:
             rc, rc_o = self.nb_row_const, get("lgx1", (n,), torch.float32)

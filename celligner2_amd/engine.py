@@ -276,12 +276,15 @@ class StepEngine:
             return p.detach()
         sh = self._shadow.get(name)
         if sh is None or sh.shape != p.shape:
-            if p.dim() == 2 and p.shape[1] % 8:
+            if p.dim() == 2 and (p.shape[0] % 8 or p.shape[1] % 8):
                 # rows of a width that is not a multiple of 8 elements: leading dimension rounded up, pad zeroed once
-                # (see abuf); this copy is converted here, after every optimizer step, not inside the Adam kernel
-                # (which addresses a contiguous copy): shadow_for_adam() does not hand it out
-                ldp = (p.shape[1] + 7) // 8 * 8
-                sh = torch.zeros((p.shape[0], ldp), dtype=torch.bfloat16, device=self.dev)[:, :p.shape[1]]
+                # (see abuf); such a copy is converted here, after every optimizer step, not inside the Adam kernel
+                # (which addresses a contiguous copy): shadow_for_adam() does not hand it out.
+                # A row COUNT that is not a multiple of 8 (the output layer's [G, H] at a gene count like 19 004): zero
+                # rows up to the next multiple, so that the input gradient's reduction over the genes can run over the
+                # padded count (_dgrad); the [G, H] view stays contiguous and the Adam kernel keeps refreshing it.
+                r8, ldp = (p.shape[0] + 7) // 8 * 8, (p.shape[1] + 7) // 8 * 8
+                sh = torch.zeros((r8, ldp), dtype=torch.bfloat16, device=self.dev)[:p.shape[0], :p.shape[1]]
             else:
                 sh = torch.empty(p.shape, dtype=torch.bfloat16, device=self.dev)
             self._shadow[name] = sh
@@ -436,16 +439,28 @@ class StepEngine:
 
     def _fwd(self, a, wname, y, bias=None):
         """y = a @ W^T (+ bias), unsplit."""
-        w = self.weight(wname)
-        la, lw = self._padded_width(a), self._padded_width(w)
-        if la and la == lw:  # both zero-padded along the reduction: reduce over the padded width (16-byte chunks)
-            a = a.as_strided((a.shape[0], la), (la, 1), a.storage_offset())
-            w = w.as_strided((w.shape[0], lw), (lw, 1), w.storage_offset())
+        a, w = self._widened(a, self.weight(wname))
         a2, w2, _ = self._pair(a, w, a.shape[0], w.shape[0], w.shape[1], wy=wname)
         ops.linear_fwd(a2, w2, y, bias=bias, x3=self.x3)
 
+    def _widened(self, a, w):
+        """Operands of y = a @ w^T that are both zero-padded along the reduction (abuf / weight() / the dataset's resident
+        encoder input at a width that is not a multiple of 8): views over the padded width, so that the reduction runs in
+        16-byte chunks and adds exact zeros."""
+        la, lw = self._padded_width(a), self._padded_width(w)
+        if la and la == lw:
+            a = a.as_strided((a.shape[0], la), (la, 1), a.storage_offset())
+            w = w.as_strided((w.shape[0], lw), (lw, 1), w.storage_offset())
+        return a, w
+
     def _dgrad(self, dy, wname, out_slabs, alpha=None):
         w = self.weight(wname)
+        ld = self._padded_width(dy)
+        if ld and w.dtype == dy.dtype and w.shape[0] == dy.shape[1] and w.is_contiguous() and w.shape[1] % 8 == 0 \
+                and w.untyped_storage().nbytes() >= (w.storage_offset() + ld * w.shape[1]) * 2:
+            # reduction over a gene count that is not a multiple of 8: dy's pad columns and w's pad rows are zero
+            dy = dy.as_strided((dy.shape[0], ld), (ld, 1), dy.storage_offset())
+            w = w.as_strided((ld, w.shape[1]), (w.shape[1], 1), w.storage_offset())
         d2, w2, _ = self._pair(dy, w, dy.shape[0], w.shape[1], w.shape[0], wy=wname)
         ops.linear_dgrad(d2, w2, out_slabs, nslab=out_slabs.shape[0], alpha=alpha, x3=self.x3)
 
@@ -457,12 +472,15 @@ class StepEngine:
 
     def _linear_slabs(self, key, a, wname, B):
         w = self.weight(wname)
-        N, K = w.shape
         if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): the batch is read in place
+            af, w = self._widened(a[0], w)
+            N, K = w.shape
             ns = ops.pick_nslab(B, N, K, w.dtype, self.x3)
             y = self.buf(key + ".Y", (ns, B, N))
-            ops.linear_fwd_rows(a[0], a[1], B, w, y, nslab=ns)
+            ops.linear_fwd_rows(af, a[1], B, w, y, nslab=ns)
             return y
+        a, w = self._widened(a, w)
+        N, K = w.shape
         a2, w2, pl = self._pair(a, w, B, N, K, wy=wname)
         ns = ops.pick_nslab(B, N, K, a.dtype, self.x3, planes=pl)
         y = self.buf(key + ".Y", (ns, B, N))
@@ -555,6 +573,10 @@ class StepEngine:
         cut = (full * 256 // per) * 256  # rows (tm >= tn) or columns of the output covered by the full rounds
         by_rows = tm >= tn
         rest = (N if by_rows else K) - cut
+        # (the strip is a problem of its own: the transposed-operand and row-indexed entry points exist for the 256x256
+        # kernel only and refuse what it does not take -- a strip of 1456 x 976 at 17 840 genes x 976 was below its size)
+        if ops.gemm_tile(dy.dtype, rest if by_rows else N, K if by_rows else rest, M, self.x3) != 256:
+            return False
         tiles2 = ((rest + 255) // 256) * per
         ns = max(1, min(16, 256 // tiles2, M // 256))
         if by_rows:
@@ -750,7 +772,7 @@ class StepEngine:
         elif x is None:
             raise ValueError("a batch without x needs xin in the encoder's operand dtype")
         elif log_in or xt != F32:
-            xin = self.buf("xin", (B, G), xt)
+            xin = self.abuf("xin", (B, G), xt)
             ops.prep_input(x, xin, log_in)
         else:
             xin = x
@@ -785,7 +807,7 @@ class StepEngine:
         logits = self.buf("logits", (B, G))
         self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
         # ---- reconstruction loss (+ its unit-upstream gradient)
-        dlogits = self.buf("dlogits", (B, G), self.head_t)
+        dlogits = self.abuf("dlogits", (B, G), self.head_t)
         if cfg["recon_loss"] == "nb":
             C = cfg["n_conditions"]
             ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
@@ -808,7 +830,7 @@ class StepEngine:
         else:  # zinb: second gene-width head for the dropout logits (modules.py:471-477, celligner2.py:286-296)
             pi = self.buf("pi", (B, G))
             self._fwd(d, self.head2 + ".weight", pi, bias=self.p[self.head2 + ".bias"].detach())
-            dpi = self.buf("dpi", (B, G), self.head_t)
+            dpi = self.abuf("dpi", (B, G), self.head_t)
             C = cfg["n_conditions"]
             ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
             if x is None:
@@ -996,7 +1018,7 @@ class StepEngine:
         cfg = self.cfg
         B, G = x.shape
         if cfg["applylog"] or self.enc[0].gt != F32:
-            xin = self.buf("xin", (B, G), self.enc[0].gt)
+            xin = self.abuf("xin", (B, G), self.enc[0].gt)
             ops.prep_input(x, xin, cfg["applylog"])  # get_latent applies the log for every recon loss (:398-399)
         else:
             xin = x

@@ -47,3 +47,33 @@ def test_gene_count_not_a_multiple_of_8_at_a_large_batch():
     for prec in ("fp32", "bf16"):
         bad, _ = fz.run_case(c, prec, 5)
         assert not bad, (prec, bad)
+
+
+def test_two_part_weight_gradient_with_a_strip_below_the_256_kernel():
+    """Found by tools/fuzz_trainer.py --big (17 840 genes, hidden [976, 240], batch 4096, bf16 mode): the decoder's weight
+    gradient [17840, 976] is 280 tiles of 256x256 -- one full round of the chip plus a strip of 1456 x 976, which is below
+    the 256x256 kernel's size and was refused by the transposed-operand entry point.  Same dispatch at a size the oracle
+    reaches is not available (the two-part split needs > 256 tiles), so the step is run at that size in both precisions and
+    the bf16 gradients are held against fp32 mode's."""
+    import torch
+    from celligner2_amd.model import Celligner2
+    G, hidden, L, C, B = 17840, [976, 240], 23, 4, 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    x = torch.poisson(torch.exp(torch.randn(1, G, device="cuda", generator=g) + 0.5).expand(B, G).contiguous(), generator=g)
+    cond = torch.zeros(B, C, dtype=torch.int64, device="cuda")
+    cond[torch.arange(B, device="cuda"), torch.randint(0, C, (B,), device="cuda", generator=g)] = 1
+    eps = torch.randn(B, L, device="cuda", generator=g)
+    batch = dict(x=x, batch=cond, sizefactor=x.sum(1), goodloc=torch.ones(B, G, dtype=torch.bool, device="cuda"))
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        m = Celligner2(G, hidden, L, 0.0, False, "nb", conditions=[f"c{i}" for i in range(C)], precision=prec).cuda().train()
+        m._forced_noise = dict(eps=eps, masks={})
+        r, k, mm, ce = m(**batch)
+        (r + 1e-3 * k + mm + ce).backward()
+        m._engine().check_status()
+        grads[prec] = {n: p.grad.double() for n, p in m.named_parameters() if p.grad is not None}
+    for n, g32 in grads["fp32"].items():
+        e = float((grads["bf16"][n] - g32).norm() / g32.norm().clamp_min(1e-30))
+        assert e < 3e-2, (n, e)
