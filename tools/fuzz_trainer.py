@@ -112,9 +112,11 @@ def main():
             try:
                 bad, sizes, logs[prec] = run_case(c, prec, a.seed * 1000 + i)
                 if a.big and prec == "bf16" and "fp32" in logs:
-                    # (the KL term is the sensitive one: 2.5 % apart after two epochs was seen, everything else below 1 %)
+                    # (the KL term is the sensitive one: 2.5 % apart after two epochs was seen, 10 % of a KL of 0.6 behind a LayerNorm
+                    # over 8 units; everything else below 1 %)
                     for k, rt in (("epoch_loss", 2e-2), ("val_loss", 2e-2), ("epoch_recon_loss", 2e-2), ("epoch_kl_loss", 1e-1)):
-                        if k in logs["fp32"] and not np.allclose(logs["bf16"][k], logs["fp32"][k], rtol=rt):
+                        if k in logs["fp32"] and not np.allclose(logs["bf16"][k], logs["fp32"][k], rtol=rt,
+                                                                 atol=0.1 if k == "epoch_kl_loss" else 0.0):
                             bad.append(f"log {k}: bf16 {logs['bf16'][k]} vs fp32 {logs['fp32'][k]}")
             except Exception as e:
                 bad, sizes = [f"{type(e).__name__}: {e}"], None
