@@ -45,7 +45,8 @@ def draw_case(rng):
     # (MMD on a latent space of a few dimensions: its sharpest kernels, exp(-5e5 d^2), make the gradient a discontinuous
     # function of z in any finite precision -- seen at L = 2: 3e-3 in fp32 mode, tens of percent in bf16 mode)
     L = int(rng.integers(8 if use_mmd else 2, 70))
-    return dict(G=G, hidden=hidden, L=L, C=int(rng.integers(0 if recon == "mse" else 2, 5)),
+    mmd_opt = int(rng.integers(0, 4))  # 1: a main dataset (its rows form the first partition), 2: mmd_boundary
+    return dict(G=G, hidden=hidden, L=L, mmd_opt=mmd_opt, mmd_b=int(rng.integers(1, 4)), C=int(rng.integers(0 if recon == "mse" else 2, 5)),
                 P=int(rng.choice([0, 3, 30, 65])), B=B, recon=recon,
                 use_mmd=use_mmd, mmd_on=["z", "y"][int(rng.integers(0, 2))],
                 # (use_bn on a batch of a few rows: statistics of two values, gradients ill-conditioned in any precision)
@@ -77,9 +78,15 @@ def run_case(c, precision, seed):
     rng = np.random.default_rng(seed)
     G, L, C, P, B = c["G"], c["L"], c["C"], c["P"], c["B"]
     use_mmd = c["use_mmd"] and C > 1
+    # (MMD options only where every condition is sure to occur in the batch: the reference raises otherwise)
+    opt = c.get("mmd_opt", 0) if (use_mmd and B >= 64) else 0
+    main = 0 if opt == 1 else None
+    boundary = min(c.get("mmd_b", 1), C - 1) if opt == 2 else None
+    extra = dict(main_dataset="c0") if main is not None else (dict(mmd_boundary=boundary) if boundary else {})
     cfg = orc.Cfg(input_dim=G, hidden_layer_sizes=c["hidden"], latent_dim=L, n_conditions=C, n_predictors=P,
                   classifier_hidden_layer_sizes=c["cls_hidden"], recon_loss=c["recon"], use_own_kl=c["own_kl"],
-                  use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0, use_bn=c["use_bn"])
+                  use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0, use_bn=c["use_bn"], main_dataset=main,
+                  mmd_boundary=boundary)
     params = orc.init_params(cfg, seed, np.float32)
     buffers = {}
     for k, shp in orc.buffer_shapes(cfg).items():
@@ -127,7 +134,7 @@ def run_case(c, precision, seed):
         m = Celligner2(G, c["hidden"], L, 0.0, c["own_kl"], c["recon"], c["use_bn"],
                        conditions=[f"c{i}" for i in range(C)], use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0,
                        predictors=[f"p{i}" for i in range(P)], classifier_hidden_layer_sizes=c["cls_hidden"],
-                       precision=precision)
+                       precision=precision, **extra)
     m.load_state_dict({k: torch.tensor(v) for k, v in {**params, **buffers}.items()})
     m.to(DEV).train()
     for n, p in m.named_parameters():
@@ -209,7 +216,7 @@ def run_case(c, precision, seed):
         m2 = Celligner2(G, c["hidden"], L, 0.0, c["own_kl"], c["recon"], c["use_bn"],
                         conditions=[f"c{i}" for i in range(C)], use_mmd=use_mmd, mmd_on=c["mmd_on"], beta=10.0,
                         predictors=[f"p{i}" for i in range(P)], classifier_hidden_layer_sizes=c["cls_hidden"],
-                        precision=precision)
+                        precision=precision, **extra)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     if c["use_bn"]:  # the fresh module repeats the tracked forward from the statistics the first one started from
         sd.update({k: v.clone() for k, v in bn_before.items()})
