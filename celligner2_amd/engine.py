@@ -575,7 +575,8 @@ class StepEngine:
         rest = (N if by_rows else K) - cut
         # (the strip is a problem of its own: the transposed-operand and row-indexed entry points exist for the 256x256
         # kernel only and refuse what it does not take -- a strip of 1456 x 976 at 17 840 genes x 976 was below its size)
-        if ops.gemm_tile(dy.dtype, rest if by_rows else N, K if by_rows else rest, M, self.x3) != 256:
+        strict = isinstance(a, (tuple, _T)) or isinstance(dy, _T)
+        if strict and ops.gemm_tile(dy.dtype, rest if by_rows else N, K if by_rows else rest, M, self.x3) != 256:
             return False
         tiles2 = ((rest + 255) // 256) * per
         ns = max(1, min(16, 256 // tiles2, M // 256))
@@ -804,25 +805,51 @@ class StepEngine:
             d = self._block_fwd(blk, d, cond, masks, train, save)
         self._dlast = d
         y1 = self._ws["dec0.act"]
-        logits = self.buf("logits", (B, G))
+        # A gene count that is not a multiple of 4 with the NB likelihood on resident rows: the loss runs over G4 = G rounded
+        # up, on operands that all have rows of that width -- the dataset's padded copies (DeviceDataset.resident_rows4:
+        # mask 0 in the pad), logits with -inf in the pad (a softmax weight of exactly 0), dispersion rows of zeros -- so
+        # that its 16-byte row walk applies (910 -> ~220 us at 4096 x 19 001); the pad genes are masked genes.
+        G4 = (G + 3) // 4 * 4
+        wide4 = (G4 != G and cfg["recon_loss"] == "nb" and x is None and batch["x_full"].stride(0) == G4
+                 and batch["goodloc_full"].stride(0) == G4)
+        if wide4:
+            logits4 = self.buf("logits4", (B, G4))
+            logits4[:, G:].fill_(-float("inf"))
+            logits = self._ws["logits"] = logits4[:, :G]
+        else:
+            logits = self.buf("logits", (B, G))
         self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
         # ---- reconstruction loss (+ its unit-upstream gradient)
         dlogits = self.abuf("dlogits", (B, G), self.head_t)
+        if wide4 and dlogits.stride(0) < G4:  # (fp32 mode: abuf pads 2-byte rows only)
+            dlogits = self._ws["dlogits"] = self.buf("dlogits4", (B, G4), self.head_t, zero=True)[:, :G]
         if cfg["recon_loss"] == "nb":
             C = cfg["n_conditions"]
-            ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
             if x is None:
                 xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
             else:
                 xs, gl, ridx = x, batch["goodloc"], None
             # the loss kernel also sums dlogits over the batch (the output layer's bias gradient) while it has them
-            dbu = None
-            if save and self.p[self.head + ".bias"].requires_grad:
-                dbu = self.buf("dbias.unit", (G,))
-            self._ws["dbias.unit"] = dbu
-            ops.recon_nb(logits, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
-                         losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
-                         lgx1=batch.get("lgx1"), row_index=ridx, dbias=dbu)
+            want_db = save and self.p[self.head + ".bias"].requires_grad
+            theta = self.p["theta"].detach()
+            if wide4:
+                widen = lambda t: t.as_strided((t.shape[0], G4), (t.stride(0), 1), t.storage_offset())  # noqa: E731
+                th4 = self.buf("theta4", (G4,) + tuple(theta.shape[1:]), zero=True)
+                th4[:G].copy_(theta)
+                dth4 = self.buf("dtheta.unit4", th4.shape)
+                dbu4 = self.buf("dbias.unit4", (G4,)) if want_db else None
+                ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G4, C),))
+                ops.recon_nb(logits4, widen(xs), widen(gl), batch["sizefactor"], th4, cond, inv_B, losses[0:1],
+                             widen(dlogits), dth4, ws, status[0:1], lgx1=batch.get("lgx1"), row_index=ridx, dbias=dbu4)
+                self._ws["dtheta.unit"] = dth4[:G]
+                self._ws["dbias.unit"] = dbu4[:G] if want_db else None
+            else:
+                ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
+                dbu = self.buf("dbias.unit", (G,)) if want_db else None
+                self._ws["dbias.unit"] = dbu
+                ops.recon_nb(logits, xs, gl, batch["sizefactor"], theta, cond, inv_B,
+                             losses[0:1], dlogits, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
+                             lgx1=batch.get("lgx1"), row_index=ridx, dbias=dbu)
         elif cfg["recon_loss"] == "mse":
             if x is None:
                 raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")

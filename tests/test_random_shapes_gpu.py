@@ -77,3 +77,47 @@ def test_two_part_weight_gradient_with_a_strip_below_the_256_kernel():
     for n, g32 in grads["fp32"].items():
         e = float((grads["bf16"][n] - g32).norm() / g32.norm().clamp_min(1e-30))
         assert e < 3e-2, (n, e)
+
+
+@pytest.mark.parametrize("precision,G", [("fp32", 2051), ("bf16", 2051), ("bf16", 2050), ("fp32", 701)])
+def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precision, G):
+    """The NB likelihood on the dataset's resident rows runs over the gene count rounded up to 4 (padded copies of the
+    counts and the mask, -inf logits and zero dispersion rows in the pad: engine._forward, DeviceDataset.resident_rows4) so
+    that the loss kernel's 16-byte row walk applies.  Pinned against the same step on gathered copies of the rows, which
+    takes the general kernel on the unpadded operands: losses and every gradient (two kernels, two summation orders)."""
+    import torch
+    from celligner2_amd.dataset import DeviceDataset
+    from celligner2_amd.model import Celligner2
+    N, B, L, C = 600, 256, 12, 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(G)
+    X = torch.poisson(torch.exp(torch.randn(1, G, device="cuda", generator=g) + 0.5).expand(N, G).contiguous(), generator=g)
+    good = torch.rand(N, G, device="cuda", generator=g) > 0.01
+    cond = torch.zeros(N, C, dtype=torch.int64, device="cuda")
+    cond[torch.arange(N, device="cuda"), torch.randint(0, C, (N,), device="cuda", generator=g)] = 1
+    data = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None)
+    idx = torch.randperm(N, device="cuda", generator=g)[:B]
+    eps = torch.randn(B, L, device="cuda", generator=g)
+    torch.manual_seed(1)
+    m = Celligner2(G, [96, 40], L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=5.0,
+                   precision=precision).cuda().train()
+    xt = m._engine().enc[0].gt
+    out = {}
+    for resident in (True, False):
+        batch = dict(data.gather(idx, xin_dtype=xt, apply_log=True, nb_const=True, resident_rows=resident))
+        assert ("x_full" in batch) == resident
+        if resident:
+            assert batch["x_full"].stride(0) == (G + 3) // 4 * 4 and batch["goodloc_full"].stride(0) == (G + 3) // 4 * 4
+        m._forced_noise = dict(eps=eps, masks={})
+        for p in m.parameters():
+            p.grad = None
+        total, v = m.forward_total((1.0, 1e-3, 1.0, 1.0), **batch)
+        total.backward(gradient=torch.ones((), device="cuda"))
+        m._engine().check_status()
+        out[resident] = (v.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    (v1, g1), (v0, g0) = out[True], out[False]
+    assert torch.isfinite(v1).all() and torch.allclose(v1, v0, rtol=2e-5, atol=1e-6), (v1, v0)
+    tol = 2e-4 if precision == "fp32" else 2e-2  # (bf16 mode: the two kernels round dlogits from sums in two orders)
+    for n in g0:
+        e = float((g1[n].double() - g0[n].double()).norm() / g0[n].double().norm().clamp_min(1e-30))
+        assert e < tol, (n, e)
