@@ -810,7 +810,7 @@ class StepEngine:
         # mask 0 in the pad), logits with -inf in the pad (a softmax weight of exactly 0), dispersion rows of zeros -- so
         # that its 16-byte row walk applies (910 -> ~220 us at 4096 x 19 001); the pad genes are masked genes.
         G4 = (G + 3) // 4 * 4
-        wide4 = (G4 != G and cfg["recon_loss"] == "nb" and x is None and batch["x_full"].stride(0) == G4
+        wide4 = (G4 != G and cfg["recon_loss"] in ("nb", "zinb") and x is None and batch["x_full"].stride(0) == G4
                  and batch["goodloc_full"].stride(0) == G4)
         if wide4:
             logits4 = self.buf("logits4", (B, G4))
@@ -855,18 +855,35 @@ class StepEngine:
                 raise ValueError("the MSE reconstruction needs the gathered x (resident_rows is an NB-only path)")
             ops.recon_mse(logits, xin if xin.dtype == F32 else x, batch["goodloc"], inv_B, losses[0:1], dlogits, red_ws_mse)
         else:  # zinb: second gene-width head for the dropout logits (modules.py:471-477, celligner2.py:286-296)
-            pi = self.buf("pi", (B, G))
+            if wide4:  # (as for NB above; the dropout logits of a pad gene are zeros, and masked)
+                pi4 = self.buf("pi4", (B, G4), zero=True)
+                pi = self._ws["pi"] = pi4[:, :G]
+            else:
+                pi = self.buf("pi", (B, G))
             self._fwd(d, self.head2 + ".weight", pi, bias=self.p[self.head2 + ".bias"].detach())
             dpi = self.abuf("dpi", (B, G), self.head_t)
+            if wide4 and dpi.stride(0) < G4:
+                dpi = self._ws["dpi"] = self.buf("dpi4", (B, G4), self.head_t, zero=True)[:, :G]
             C = cfg["n_conditions"]
-            ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
             if x is None:
                 xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
             else:
                 xs, gl, ridx = x, batch["goodloc"], None
-            ops.recon_zinb(logits, pi, xs, gl, batch["sizefactor"], self.p["theta"].detach(), cond, inv_B,
-                           losses[0:1], dlogits, dpi, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
-                           row_index=ridx, lgx1=batch.get("lgx1"))
+            theta = self.p["theta"].detach()
+            if wide4:
+                widen = lambda t: t.as_strided((t.shape[0], G4), (t.stride(0), 1), t.storage_offset())  # noqa: E731
+                th4 = self.buf("theta4", (G4,) + tuple(theta.shape[1:]), zero=True)
+                th4[:G].copy_(theta)
+                dth4 = self.buf("dtheta.unit4", th4.shape)
+                ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G4, C),))
+                ops.recon_zinb(logits4, pi4, widen(xs), widen(gl), batch["sizefactor"], th4, cond, inv_B, losses[0:1],
+                               widen(dlogits), widen(dpi), dth4, ws, status[0:1], row_index=ridx, lgx1=batch.get("lgx1"))
+                self._ws["dtheta.unit"] = dth4[:G]
+            else:
+                ws = self.buf("nb.ws", (ops.recon_nb_ws(B, G, C),))
+                ops.recon_zinb(logits, pi, xs, gl, batch["sizefactor"], theta, cond, inv_B,
+                               losses[0:1], dlogits, dpi, self.buf("dtheta.unit", self.p["theta"].shape), ws, status[0:1],
+                               row_index=ridx, lgx1=batch.get("lgx1"))
         # ---- classifier
         classes = batch.get("classes")
         self._has_cls = classes is not None

@@ -79,8 +79,9 @@ def test_two_part_weight_gradient_with_a_strip_below_the_256_kernel():
         assert e < 3e-2, (n, e)
 
 
+@pytest.mark.parametrize("recon", ["nb", "zinb"])
 @pytest.mark.parametrize("precision,G", [("fp32", 2051), ("bf16", 2051), ("bf16", 2050), ("fp32", 701)])
-def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precision, G):
+def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precision, G, recon):
     """The NB likelihood on the dataset's resident rows runs over the gene count rounded up to 4 (padded copies of the
     counts and the mask, -inf logits and zero dispersion rows in the pad: engine._forward, DeviceDataset.resident_rows4) so
     that the loss kernel's 16-byte row walk applies.  Pinned against the same step on gathered copies of the rows, which
@@ -99,7 +100,7 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     idx = torch.randperm(N, device="cuda", generator=g)[:B]
     eps = torch.randn(B, L, device="cuda", generator=g)
     torch.manual_seed(1)
-    m = Celligner2(G, [96, 40], L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=5.0,
+    m = Celligner2(G, [96, 40], L, 0.0, False, recon, conditions=["a", "b", "c"], use_mmd=True, beta=5.0,
                    precision=precision).cuda().train()
     xt = m._engine().enc[0].gt
     out = {}
