@@ -4,6 +4,10 @@ optimizer in fp32 and bf16 mode, SyncBN), each compared by the worker with the s
 The shapes exercise the gradient arena's bucket padding and the cut of every bucket into `world` aligned chunks.
 
     python tools/fuzz_ddp.py --cases 6 --seed 0
+
+Seen once in ~100 launches (8 ranks on the one card, shape 2193,28,72,122,111,94): one rank ended with SIGABRT after
+rank 0 had already printed its passing comparison, i.e. while the processes were shutting down; the same launch passed
+when run again, and nothing in its output named a cause.  Recorded here, not explained.
 """
 import argparse
 import os
@@ -32,7 +36,13 @@ def main():
         L = int(rng.integers(8, 40))
         B = world * int(rng.integers(8, 40))  # equal shares (the MMD all-gather needs that)
         shape = ",".join(str(v) for v in [G, L, B] + hidden)
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2_DDP_SHAPE=shape, C2_DDP_PARAM_TOL_LR="0.15")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2_DDP_SHAPE=shape, C2_DDP_PARAM_TOL_LR="0.15",
+                   # two steps: the second one runs on the exchanged / all-gathered parameters.  More steps at these small
+                   # per-rank batches compare two trajectories, not two implementations: one unit on the other side of a
+                   # ReLU (kernels 1e-6 apart) is 1/24 of a gradient at 24 rows per rank, and the runs drift apart from
+                   # there (traced with C2_DDP_DUMP=1 on shape 2459,23,48,128,62: equal to 2e-5 after two steps, first
+                   # sign disagreement at step 3).  The pinned tests keep six steps at their fixed shape.
+                   C2_DDP_STEPS="2")
         port += 1
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
