@@ -30,7 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_JSON = "r02_gemm_pmc.json"  # HBM traffic of the gene-width GEMM launches (tools/pmc_step_json.py)
+PMC_JSON = "r03_gemm_pmc.json"  # HBM traffic of the gene-width GEMM launches (tools/pmc_step_json.py)
 
 CONFIGS = {
     # name: G, hidden, latent, C, P, cls_hidden, per-GPU batch, N rows, beta
@@ -161,7 +161,8 @@ def main():
                     help="warm-up and the K timed steps only (no steady-state loop, no all-terms leg, no CPU baseline): "
                          "what the rocprofv3 passes run, so that dispatch counts divide by W+K")
     ap.add_argument("--graph", type=int, default=-1, help="1/0: replay the step as a HIP graph (default: the config's)")
-    ap.add_argument("--steady-seconds", type=float, default=1.2, help="length of the second, longer timing loop")
+    ap.add_argument("--steady-seconds", type=float, default=8.0,
+                    help="length of the second, longer timing loop (long enough for a 5 s utilisation sampler to see it)")
     args = ap.parse_args()
 
     backend = os.environ.get("C2_BENCH_BACKEND", "nccl")
@@ -405,10 +406,16 @@ def main():
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM bytes per GEMM launch: measured in separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
         # profiles/*_gemm_pmc.json); only valid for the configuration it was measured on
-        traffic = None
+        traffic, traffic_note = None, None
         pmc = os.path.join(ROOT, "profiles", PMC_JSON)
         if args.config == "c4" and args.precision == "bf16" and B == CONFIGS["c4"]["B"] and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+            rec = json.load(open(pmc))
+            # the counter passes must have seen the launches this run timed: same number of gene-width launches per step
+            if abs(rec["launches_per_step"] - n_launch / args.steps) < 1e-6:
+                traffic = rec["traffic_bytes_per_launch"]
+            else:
+                traffic_note = (f"profiles/{PMC_JSON} holds {rec['launches_per_step']} launches per step, this run timed "
+                                f"{n_launch / args.steps}: not the same launch set, traffic withheld")
         H1 = cfg["hidden"][0]
         out = {
             "metric": "training cells/sec (fwd+bwd+Adam) at 19k genes" if cfg["G"] == 19000 else
@@ -432,8 +439,9 @@ def main():
                              "ms_per_step": 1e3 * dt_ss / n_steady, "seconds": dt_ss},
             "all_terms_in_step": all_in_step,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": "c2::wide::gemm_wide_kernel<*,*,8> (gene-width Linear fwd/dgrad/wgrad)",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": "c2::wide::gemm_wide_kernel<*,*,8,*> + c2::wide::gemm_wide16_kernel<*,*,*> "
+                                   "(gene-width Linear fwd / dgrad / wgrad)",
                          "timed_in": "the K timed steps" if not use_graph else "the same K steps launched without the graph",
                          "launches_per_step": n_launch / args.steps, "avg_launch_ms": gemm_ms / n_launch,
                          "gemm_ms_per_step": gemm_ms / args.steps, "gemm_flops_per_step": gemm_flops / args.steps,

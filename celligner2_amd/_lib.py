@@ -91,6 +91,7 @@ _SIGS = {
     "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),
     "c2_defer_loss_sums": (i32, [i32]),
     "c2_scale4": (i32, [vp, f32, f32, f32, f32, vp, vp]),
+    "c2_decoder_output": (i32, [vp, i64, i64, i64, i32, vp, i64, vp]),
     "c2_scale": (i32, [vp, vp, vp, i64, vp]),
     "c2_axpy": (i32, [vp, vp, vp, i64, vp]),
     "c2_dropout_masks": (i32, [vp, i64, f32, C.c_uint64, C.c_uint64, vp]),

@@ -1749,3 +1749,44 @@ extern "C" int c2_classifier_loss_fwd_bwd(const float* u, int64_t ldu, int64_t* 
     C2_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- decoder output activation of the inference path (Decoder.forward, modules.py:467-482, as reconstructLatent returns
+// it: celligner2.py:411-420): Softmax(dim=-1) of the NB / ZINB mean head, ReLU of the MSE head.  One workgroup per row;
+// the row is read twice (max + sum of exponentials in one online pass, then the normalised write) -- the second read of a
+// 76 KB row comes from L2.
+namespace c2 {
+__global__ void __launch_bounds__(256) decoder_output_kernel(const float* __restrict__ logits, int64_t ldl, int64_t B,
+                                                             int64_t G, int mode, float* __restrict__ out, int64_t ldo) {
+    __shared__ float red[32];
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* row = logits + b * ldl;
+        float* o = out + b * ldo;
+        if (mode == 1) {  // ReLU
+            for (int64_t g = threadIdx.x; g < G; g += 256) o[g] = fmaxf(row[g], 0.f);
+            continue;
+        }
+        float mx = -INFINITY;
+        for (int64_t g = threadIdx.x; g < G; g += 256) mx = fmaxf(mx, row[g]);
+        mx = block_max<256>(mx, red);
+        float s = 0.f;
+        for (int64_t g = threadIdx.x; g < G; g += 256) s += __expf(row[g] - mx);
+        s = block_sum<256>(s, red);
+        const float inv = 1.0f / s;
+        for (int64_t g = threadIdx.x; g < G; g += 256) o[g] = __expf(row[g] - mx) * inv;
+        __syncthreads();  // red is reused by the next row
+    }
+}
+}  // namespace c2
+
+extern "C" int c2_decoder_output(const float* logits, int64_t ldl, int64_t B, int64_t G, int mode, float* out, int64_t ldo,
+                                 void* stream) {
+    C2_CHECK(mode == 0 || mode == 1, "mode: 0 = softmax over the genes, 1 = ReLU");
+    C2_CHECK(B >= 0 && G >= 0, "negative size");
+    if (B == 0 || G == 0) return 0;
+    C2_CHECK(logits && out && ldl >= G && ldo >= G, "bad arguments");
+    const int grid = (int)std::min<int64_t>(B, 4096);
+    hipLaunchKernelGGL(c2::decoder_output_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ldl, B, G, mode, out,
+                       ldo);
+    C2_LAUNCH_CHECK();
+    return 0;
+}

@@ -606,7 +606,7 @@ class Celligner2(nn.Module):
         latent = torch.as_tensor(latent, device=next(self.parameters()).device).float().contiguous()
         logits, y1 = eng.decode(latent, c.long().contiguous() if c is not None else None)
         if self.recon_loss == "mse":
-            return torch.relu(logits), y1.float().clone()
+            return ops.decoder_output(logits, "relu"), y1.float().clone()
         if self.recon_loss == "zinb":  # Decoder.forward returns (mean, dropout logits, y1), modules.py:506-509
-            return torch.softmax(logits, dim=-1), eng._ws["pi"].clone(), y1.float().clone()
-        return torch.softmax(logits, dim=-1), y1.float().clone()
+            return ops.decoder_output(logits, "softmax"), eng._ws["pi"].clone(), y1.float().clone()
+        return ops.decoder_output(logits, "softmax"), y1.float().clone()

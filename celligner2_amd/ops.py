@@ -690,3 +690,14 @@ def dropout_masks_dev(out, p_drop, seed, offset_dev, advance):
     check(lib.c2_dropout_masks_dev(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), ptr(offset_dev),
                                    int(advance), stream()))
     return out
+
+
+def decoder_output(logits, mode):
+    """Softmax over the genes ("softmax") or ReLU ("relu") of the decoder's output layer, a new [B, G] fp32 tensor
+    (reconstructLatent, celligner2.py:411-420)."""
+    L.require_gpu(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    out = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    check(lib.c2_decoder_output(ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1],
+                                {"softmax": 0, "relu": 1}[mode], ptr(out), out.stride(0), stream()))
+    return out

@@ -382,6 +382,12 @@ int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* str
 int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev, uint64_t advance,
                          void* stream);
 
+/* Output activation of the decoder on the inference path -- Decoder.forward (celligner2/model/modules.py:467-482) as
+ * Celligner2.reconstructLatent returns it (celligner2/model/celligner2.py:411-420): mode 0 = nn.Softmax(dim=-1) over the
+ * genes (NB / ZINB mean head), mode 1 = nn.ReLU (MSE head).  logits [B,G] fp32 (row stride ldl) -> out [B,G] fp32. */
+int c2_decoder_output(const float* logits, int64_t ldl, int64_t B, int64_t G, int mode, float* out, int64_t ldo,
+                      void* stream);
+
 /* y[i] = a*x[i] (a = *a_dev), fp32. */
 int c2_scale(const float* x, const float* a_dev, float* y, int64_t n, void* stream);
 

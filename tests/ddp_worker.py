@@ -16,7 +16,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _own_stderr():
+    """Every rank keeps its own error stream: torchrun shows the tail of ONE merged stream, so the message of a rank that
+    aborts (a C++ `terminate`, a HIP runtime error) was lost once.  C2_DDP_LOG_DIR=<dir>: file
+    descriptor 2 of this rank goes to <dir>/rank<r>.err; the launcher prints those files when the run fails.  The Python
+    stacks of all threads are dumped there on SIGABRT / SIGSEGV."""
+    import faulthandler
+    d = os.environ.get("C2_DDP_LOG_DIR")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        fd = os.open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}.err"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        sys.stderr.flush()
+        os.dup2(fd, 2)
+        os.close(fd)
+    faulthandler.enable(all_threads=True)
+
+
+def _finish(ok, on_device):
+    """Orderly end of a rank: agree on the verdict, drain this rank's GPU queues (side stream included), meet the peers
+    at a barrier so that no rank closes its sockets while another is still inside a collective, only then destroy the
+    process group and leave.  (Without the barrier a fast rank's `destroy_process_group` + exit closes gloo pairs that a
+    slower peer is still reading from: the peer's transport thread raises in a context nobody catches -> SIGABRT.)"""
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if on_device else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    verdict = flag.item() == 1.0
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    sys.exit(0 if verdict else 1)
+
+
 def main():
+    _own_stderr()
     # C2_DDP_BACKEND=nccl with ONE rank (and C2_DP_SINGLE_RANK=1, so that the rank still issues every collective): the RCCL
     # branch of parallel.py -- stream-ordered exchange on the side stream, deferred last bucket, reduce-scatter and
     # all-gather through the staging chunk -- on the one GPU there is.
@@ -153,10 +186,7 @@ def main():
                 ok = False
                 print("MISMATCH param after Adam", n, err)
         print("losses ddp", losses, "single", ref_l, "worst first-step gradient error", locals().get("worst_g"))
-    flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    dist.destroy_process_group()
-    sys.exit(0 if flag.item() == 1.0 else 1)
+    _finish(ok, backend == "nccl")
 
 
 def noise_variant(rank, world):
@@ -217,10 +247,7 @@ def noise_variant(rank, world):
             if bad:
                 ok = False
                 print("MISMATCH noise variant, mode", mode, bad)
-    flag = torch.tensor([1.0 if ok else 0.0])
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    dist.destroy_process_group()
-    sys.exit(0 if flag.item() == 1.0 else 1)
+    _finish(ok, False)
 
 
 if __name__ == "__main__":

@@ -952,3 +952,21 @@ def test_sixteen_wave_form_of_the_gene_width_kernel_equals_the_eight_wave_form(t
     for k in res["8"]:
         assert torch.equal(res["8"][k], res["16"][k]), k
         assert torch.isfinite(res["8"][k]).all() and res["8"][k].abs().max() > 0
+
+
+@pytest.mark.parametrize("B,G", [(1, 7), (5, 19000), (130, 1001), (64, 25000)])
+def test_decoder_output_softmax_and_relu(B, G):
+    """c2_decoder_output: nn.Softmax(dim=-1) / nn.ReLU of the decoder's output layer on the inference path
+    (modules.py:467-482, celligner2.py:411-420) vs numpy in float64; strided rows; rows sum to one."""
+    ops = _ops()
+    rng = np.random.default_rng(B + G)
+    lg = (rng.standard_normal((B, G + 3)) * 4).astype(np.float32)
+    lg[0, : min(G, 3)] = [30.0, -40.0, 0.0][: min(G, 3)]
+    t = T(lg)[:, :G]  # row stride G + 3
+    sm = ops.decoder_output(t, "softmax").cpu().numpy()
+    e = np.exp(lg[:, :G].astype(np.float64) - lg[:, :G].max(1, keepdims=True))
+    ref = e / e.sum(1, keepdims=True)
+    assert np.abs(sm - ref).max() <= 1e-5 * ref.max()
+    assert np.abs(sm.astype(np.float64).sum(1) - 1).max() < 1e-4
+    assert np.array_equal(ops.decoder_output(t, "relu").cpu().numpy(), np.maximum(lg[:, :G], 0))
+    assert ops.decoder_output(T(np.zeros((0, 5), np.float32)), "softmax").shape == (0, 5)

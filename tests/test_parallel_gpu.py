@@ -9,13 +9,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, env, tag):
+    """The worker ranks write their error streams to files of their own (C2_DDP_LOG_DIR): shown when the run fails."""
+    logs = os.path.join(ROOT, "gpurun_out", "ddp_logs", tag)
+    r = subprocess.run(cmd, env=dict(env, C2_DDP_LOG_DIR=logs), capture_output=True, text=True, timeout=110)
+    if r.returncode != 0:
+        per_rank = ""
+        for f in sorted(os.listdir(logs)) if os.path.isdir(logs) else []:
+            per_rank += f"\n--- {f}\n" + open(os.path.join(logs, f)).read()[-3000:]
+        raise AssertionError(r.stdout[-3000:] + r.stderr[-3000:] + per_rank)
+
+
 @pytest.mark.parametrize("variant", ["ln", "bn", "noise", "shard", "shard_bf16"])
 def test_two_ranks_equal_single_process(variant):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _run(cmd, env, "gloo2_" + variant)
 
 
 @pytest.mark.parametrize("variant", ["ln", "bn", "shard", "shard_bf16"])
@@ -27,5 +37,4 @@ def test_one_rank_over_rccl_issues_every_collective(variant):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2_DDP_BACKEND="nccl", C2_DP_SINGLE_RANK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _run(cmd, env, "rccl1_" + variant)

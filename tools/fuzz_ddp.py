@@ -42,7 +42,7 @@ def main():
                    # ReLU (kernels 1e-6 apart) is 1/24 of a gradient at 24 rows per rank, and the runs drift apart from
                    # there (traced with C2_DDP_DUMP=1 on shape 2459,23,48,128,62: equal to 2e-5 after two steps, first
                    # sign disagreement at step 3).  The pinned tests keep six steps at their fixed shape.
-                   C2_DDP_STEPS="2")
+                   C2_DDP_STEPS="2", C2_DDP_LOG_DIR=os.path.join(ROOT, "gpurun_out", "ddp_logs", f"fuzz{i}"))
         port += 1
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
@@ -53,6 +53,9 @@ def main():
         print(f"[{i}] world {world} {variant} G,L,B,hidden = {shape}: {'ok' if ok else 'FAIL'} ({time.time() - t0:.0f}s)", flush=True)
         if not ok:
             print((r.stdout[-2500:] + r.stderr[-2500:]), flush=True)
+            logs = env["C2_DDP_LOG_DIR"]  # every rank's own error stream (an abort's message survives here)
+            for f in sorted(os.listdir(logs)) if os.path.isdir(logs) else []:
+                print(f"--- {f}\n" + open(os.path.join(logs, f)).read()[-2500:], flush=True)
     print(f"{fails} failure(s)")
     sys.exit(min(fails, 100))
 

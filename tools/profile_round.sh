@@ -20,7 +20,7 @@ for cfg in c4 c2; do
 done
 cd $root
 bash tools/pmc_step.sh $tag || exit 5
-cp gpurun_out/pmc_step_$tag/r02_gemm_pmc.json $out/ || exit 6
+cp gpurun_out/pmc_step_$tag/r03_gemm_pmc.json $out/ || exit 6
 timeout -k 10 300 python3 bench.py > $out/bench_c4.json 2> $out/bench_c4.err || exit 7
 timeout -k 10 300 python3 bench.py --config c2 --steps 200 --warmup 20 > $out/bench_c2.json 2> $out/bench_c2.err || exit 8
 for cfg in c1 c3 c5; do  # the other configurations of SURVEY.md 8(d): bench lines only
