@@ -256,9 +256,10 @@ def main():
         from celligner2_amd.surgery import apply_freeze
         apply_freeze(model.to(device), freeze_expression=True)
     data = synth_dataset(cfg, device)
-    # one GPU: the step is replayed as a HIP graph unless --graph 0; ranks of a data-parallel run launch it kernel by kernel
-    # (the gradient exchange is not capturable)
-    use_graph = (bool(cfg.get("graph", True)) if args.graph < 0 else bool(args.graph)) and not dp
+    # the step is replayed as a HIP graph unless --graph 0 -- in a data-parallel run over RCCL too (its collectives are
+    # captured with the kernels; a host-side gloo rehearsal cannot be).  If the collective library refuses the capture the
+    # trainer goes on launching the step kernel by kernel and the line says so ("graph_refused").
+    use_graph = (bool(cfg.get("graph", True)) if args.graph < 0 else bool(args.graph)) and (not dp or backend == "nccl")
     trainer = Celligner2Trainer(model, None, train_data=data, valid_data=None, batch_size=Bglob, use_leiden=False,
                                 alpha_kl=1e-3, monitor=False, use_early_stopping=False, rng="device", world=comm,
                                 seed=2020, n_samples=n_samples, **({"graph": True} if use_graph else {}))
@@ -356,7 +357,8 @@ def main():
     # too short for a power-managed chip to settle; `value` stays the K-step figure the contract asks for.
     if args.profile_pass:
         if rank == 0:
-            emit({"profile_pass": True, "steps": args.steps, "warmup": args.warmup, "hip_graph": use_graph,
+            emit({"profile_pass": True, "steps": args.steps, "warmup": args.warmup,
+                  "hip_graph": use_graph and trainer.graph_refused is None,
                               "ms_per_step": 1e3 * dt / args.steps, "value": cells / dt})
         if dp:
             dist.destroy_process_group()
@@ -372,6 +374,7 @@ def main():
     # Third, untuned-pipeline timing of the same K steps: every data-only term is evaluated INSIDE the step, as the
     # reference's forward does (log(1+x) of the batch, lgamma(x+1) of the NB likelihood; the batch's counts and mask
     # copied by the gather) instead of once per resident dataset.  Reported beside the headline value.
+    graph_refused = trainer.graph_refused
     if use_graph:
         trainer.drop_graph()
         trainer.graph = trainer.dataloader_train.static = False
@@ -429,7 +432,8 @@ def main():
                                    f"dataset resident in HBM, {recon.upper()} reconstruction, gene-width GEMMs {args.precision} operands "
                                    f"fp32 accumulate",
                        "global_batch": Bglob, "parallelism": f"dp{n_gpus}" + ("-rehearsal" if rehearse else ""), "backend": backend if dp else None,
-                       "epoch_rows": n_samples, "hip_graph": use_graph,
+                       "epoch_rows": n_samples, "hip_graph": use_graph and graph_refused is None,
+                       "graph_refused": graph_refused,
                        "optimizer": ("sharded over ranks (reduce-scatter, Adam on own chunks, all-gather)"
                                      if (comm is not None and comm.sharded) else "every rank updates every parameter"),
                        "dataset_resident_terms": "log(1+x) as bf16 and the per-row sum of lgamma(x+1) are evaluated once "

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C2MI_LIB") or os.path.join(_HERE, "lib", "libc2mi.so")  # C2MI_LIB: ablation builds
 
-F32, BF16, F32X3, BF16X3P = 0, 1, 2, 3
+F32, BF16, F32X3, BF16X3P, F16 = 0, 1, 2, 3, 4
 MMD_MAX_PARTS = 64
 
 if not os.path.exists(LIB_PATH):
@@ -30,17 +30,22 @@ class AdamState(C.Structure):
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp)]
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp), ("shadow_f16", i32)]
 
 
 _SIGS = {
     "c2_last_error": (C.c_char_p, []),
     "c2_version": (i32, []),
-    "c2_prep_input": (i32, [vp, i64, i64, i64, vp, i32, i64, i32, vp]),
+    "c2_prep_input": (i32, [vp, i64, i64, i64, vp, i32, i64, i32, vp, vp]),
+    "c2_col_mean_ws": (sz, [i64, i64]),
+    "c2_col_mean": (i32, [vp, i64, i64, i64, i32, vp, vp, vp]),
+    "c2_gemv_bias": (i32, [vp, i64, i64, i64, vp, vp, vp, vp]),
+    "c2_rank1_add": (i32, [vp, i64, i64, i64, vp, vp, vp]),
+    "c2_drop_pending_sums": (i32, []),
     "c2_linear_fwd": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_dgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
-    "c2_linear_fwd_rows": (i32, [vp, i64, i64, vp, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_fwd_rows": (i32, [vp, i64, i64, vp, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad_rows": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad_rows_at": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_wgrad_bt": (i32, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
@@ -83,11 +88,12 @@ _SIGS = {
     "c2_adam_step_dev": (i32, [C.POINTER(AdamTensor), i32, vp, vp]),
     "c2_combine_losses_dev": (i32, [vp, vp, vp, vp, vp]),
     "c2_scale4_dev": (i32, [vp, vp, vp, vp]),
-    "c2_dropout_masks_dev": (i32, [vp, i64, f32, C.c_uint64, vp, C.c_uint64, vp]),
+    "c2_dropout_masks_dev": (i32, [vp, i64, f32, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp]),
     "c2_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "c2_cast_f16": (i32, [vp, vp, i64, vp]),
     "c2_transpose_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
-                             vp, i64, vp]),
+                             vp, i64, vp, vp, i64, vp]),
     "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),
     "c2_defer_loss_sums": (i32, [i32]),
     "c2_scale4": (i32, [vp, f32, f32, f32, f32, vp, vp]),
@@ -131,6 +137,8 @@ def dt_code(dtype):
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {dtype}")
 
 

@@ -32,6 +32,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 // operand copies the GEMMs read: bf16(p), and bf16(p - bf16(p)) for the narrow layers' planes
 __device__ __forceinline__ void store_shadows(const c2_adam_tensor& t, int64_t i, const f32x4& p) {
     u32x2 pk;
+    if (t.shadow_f16) {  // an IEEE-half copy (the encoder's first layer in bf16 mode): no low plane
+        pk[0] = pack2<f16_t>(p[0], p[1]);
+        pk[1] = pack2<f16_t>(p[2], p[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
+        return;
+    }
     pk[0] = (unsigned)f2bf(p[0]) | ((unsigned)f2bf(p[1]) << 16);
     pk[1] = (unsigned)f2bf(p[2]) | ((unsigned)f2bf(p[3]) << 16);
     *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(t.shadow_bf16) + i) = pk;
@@ -146,7 +152,9 @@ __device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper
                 float pe = t.p[i + e], me = t.m[i + e], ve = t.v[i + e];
                 adam_one(pe, t.g[i + e], me, ve, h);
                 t.p[i + e] = pe; t.m[i + e] = me; t.v[i + e] = ve;
-                if (t.shadow_bf16) {
+                if (t.shadow_bf16 && t.shadow_f16) {
+                    reinterpret_cast<f16_t*>(t.shadow_bf16)[i + e] = (f16_t)pe;
+                } else if (t.shadow_bf16) {
                     const bf16_t hb = f2bf(pe);
                     reinterpret_cast<bf16_t*>(t.shadow_bf16)[i + e] = hb;
                     if (t.shadow_lo) reinterpret_cast<bf16_t*>(t.shadow_lo)[i + e] = f2bf(pe - bf2f(hb));
@@ -172,6 +180,7 @@ static int adam_launch(const c2_adam_tensor* desc_host, int n_tensors, const Ada
             if (d.n == 0) continue;
             C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");
             C2_CHECK(!d.shadow_lo || d.shadow_bf16, "shadow_lo without the high plane");
+            C2_CHECK(!(d.shadow_f16 && d.shadow_lo), "an f16 shadow has no low plane");
             tab.t[tab.n] = d;
             tab.first_block[tab.n] = blocks;
             blocks += (int)((d.n + kElemsPerBlock - 1) / kElemsPerBlock);

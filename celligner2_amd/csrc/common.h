@@ -47,6 +47,19 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
     return __builtin_bit_cast(float, u);
 }
 
+typedef _Float16 f16_t;  // IEEE half (C2_F16)
+// two fp32 values rounded to T (bf16_t or f16_t), packed low | high << 16
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float a, float b);
+template <>
+__device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) {
+    return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+}
+template <>
+__device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (f16_t)a) | ((unsigned)__builtin_bit_cast(unsigned short, (f16_t)b) << 16);
+}
+
 template <typename T>
 __device__ __forceinline__ float ld_as_f32(const T* p);
 template <>
@@ -60,6 +73,8 @@ template <>
 __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <>
+__device__ __forceinline__ void st_from_f32<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // log(1 + x) of a count (x >= 0) on v_log_f32 (1 ulp): 1 + x is a normal number >= 1, so none of libm's range and
 // denormal handling is needed -- the library logf costs ~30 VALU instructions per element and made the batch gather

@@ -48,7 +48,7 @@ int launch_finalize_sum(const float* partials, int n, float* out, hipStream_t st
 // ---------------------------------------------------------------------------------------------
 template <typename TO, bool VEC4>
 __global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ldx,
-                                  TO* __restrict__ out, int64_t ldo, int apply_log) {
+                                  TO* __restrict__ out, int64_t ldo, int apply_log, const float* __restrict__ center) {
     if (VEC4) {
         const int64_t cv = cols >> 2;
         const int64_t total = rows * cv;
@@ -60,13 +60,14 @@ __global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = log1p_count(v[e]);
             }
+            if (center) v -= *reinterpret_cast<const f32x4*>(center + c);
             TO* o = out + r * ldo + c;
-            if (sizeof(TO) == 4) {
+            if constexpr (sizeof(TO) == 4) {
                 *reinterpret_cast<f32x4*>(o) = v;
             } else {
                 u32x2 pk;
-                pk[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                pk[0] = pack2<TO>(v[0], v[1]);
+                pk[1] = pack2<TO>(v[2], v[3]);
                 *reinterpret_cast<u32x2*>(o) = pk;
             }
         }
@@ -77,6 +78,7 @@ __global__ void prep_input_kernel(const float* __restrict__ x, int64_t rows, int
             const int64_t r = i / cols, c = i - r * cols;
             float v = x[r * ldx + c];
             if (apply_log) v = log1p_count(v);
+            if (center) v -= center[c];
             st_from_f32<TO>(out + r * ldo + c, v);
         }
     }
@@ -662,7 +664,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     float* __restrict__ sf_out, int64_t* __restrict__ cond_out, int64_t* __restrict__ classes_out,
     TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin,
     const float* __restrict__ rowconst, float* __restrict__ rowconst_out, int32_t* __restrict__ idx32_out,
-    int64_t n, int64_t n_pad) {
+    int64_t n, int64_t n_pad, const float* __restrict__ center, bf16_t* __restrict__ xin2_out, int64_t ldxin2,
+    int vec_xin2) {
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
     if (idx32_out && threadIdx.x == 0) {
@@ -673,27 +676,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const float* xs = X + src * G;
     float* xd = x_out ? x_out + r * G : nullptr;
     const bool copy_good = goodloc && goodloc_out;
-    if (!xd && !xin_out && !copy_good) {
+    if (!xd && !xin_out && !xin2_out && !copy_good) {
         // nothing per gene: the consumers read the resident rows themselves
     } else if (vec_ok) {
         const int64_t gv = G >> 2;
         auto emit = [&](int64_t c, const f32x4& v, unsigned gm) {
             if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
-            if (xin_out) {
+            if (xin_out || xin2_out) {
                 f32x4 t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = apply_log ? log1p_count(v[e]) : v[e];
-                TX* dst = xin_out + r * ldxin + c * 4;
-                if (sizeof(TX) == 2 && vec_xin) {
-                    u32x2 pk;
-                    pk[0] = (unsigned)f2bf(t[0]) | ((unsigned)f2bf(t[1]) << 16);
-                    pk[1] = (unsigned)f2bf(t[2]) | ((unsigned)f2bf(t[3]) << 16);
-                    *reinterpret_cast<u32x2*>(dst) = pk;
-                } else if (sizeof(TX) == 4 && vec_xin) {
-                    *reinterpret_cast<f32x4*>(dst) = t;
-                } else {
+                if (center) t -= reinterpret_cast<const f32x4*>(center)[c];
+                if (xin_out) {
+                    TX* dst = xin_out + r * ldxin + c * 4;
+                    if constexpr (sizeof(TX) == 2) {
+                        if (vec_xin) {
+                            u32x2 pk;
+                            pk[0] = pack2<TX>(t[0], t[1]);
+                            pk[1] = pack2<TX>(t[2], t[3]);
+                            *reinterpret_cast<u32x2*>(dst) = pk;
+                        } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st_from_f32<TX>(dst + e, t[e]);
+                            for (int e = 0; e < 4; ++e) st_from_f32<TX>(dst + e, t[e]);
+                        }
+                    } else {
+                        if (vec_xin) {
+                            *reinterpret_cast<f32x4*>(dst) = t;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) st_from_f32<TX>(dst + e, t[e]);
+                        }
+                    }
+                }
+                if (xin2_out) {
+                    bf16_t* dst2 = xin2_out + r * ldxin2 + c * 4;
+                    if (vec_xin2) {
+                        u32x2 pk;
+                        pk[0] = pack2<bf16_t>(t[0], t[1]);
+                        pk[1] = pack2<bf16_t>(t[2], t[3]);
+                        *reinterpret_cast<u32x2*>(dst2) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst2[e] = f2bf(t[e]);
+                    }
                 }
             }
             if (copy_good) reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] = gm;
@@ -717,7 +742,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         for (int64_t c = threadIdx.x; c < G; c += 256) {
             const float v = xs[c];
             if (xd) xd[c] = v;
-            if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, apply_log ? log1p_count(v) : v);
+            const float t = (apply_log ? log1p_count(v) : v) - (center ? center[c] : 0.f);
+            if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, t);
+            if (xin2_out) xin2_out[r * ldxin2 + c] = f2bf(t);
             if (copy_good) goodloc_out[r * G + c] = goodloc[src * G + c];
         }
     }
@@ -843,8 +870,8 @@ __global__ void scale4_dev_kernel(const float* __restrict__ g, const float* __re
 // Dropout masks with the Philox counter offset in device memory; a second one-thread launch advances it after every
 // block of the mask kernel has read it (stream order).
 __global__ void dropout_mask_dev_kernel(uint8_t* __restrict__ out, int64_t n, unsigned thresh8, unsigned long long seed,
-                                        const unsigned long long* __restrict__ offset_dev) {
-    const unsigned long long offset = *offset_dev;
+                                        const unsigned long long* __restrict__ offset_dev, unsigned long long lead) {
+    const unsigned long long offset = *offset_dev + lead;
     const int64_t nvec = (n + 15) / 16;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         unsigned r[4];
@@ -880,9 +907,89 @@ __global__ void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict
         d[i] = f2bf(s[i]);
 }
 
+__global__ void cast_f16_kernel(const float* __restrict__ s, f16_t* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = (f16_t)s[i];
+}
+
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, cap));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Centred encoder input (bf16 mode).  The first layer computes h = t(x) W^T + b with t(x) = log(1 + x) (or x) rounded to
+// bf16.  Expression matrices are dominated by a per-gene level shared by all cells, so the rounding error (2^-9 of
+// |t(x)|, and 2^-9 of |W| times |t(x)|) is large against the cell-to-cell differences the gradients are made of.
+// With any fixed vector c [G]:  h = (t(x) - c) W^T + (b + W c),  dW = dh^T (t(x) - c) + (sum_b dh_b) (x) c  -- exact
+// algebra, and the bf16 operand is now the small centred part; W c and the rank-one term are formed in fp32.
+// c = the per-gene mean of t(x) over the dataset (or over the batch, for batches handed in as tensors).
+//
+// column means of t(x) over the rows, two deterministic stages (no atomics)
+__global__ __launch_bounds__(256) void col_mean_stage1(const float* __restrict__ x, int64_t ldx, int64_t rows, int64_t cols,
+                                                       int apply_log, int nsplit, float* __restrict__ part) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c >= cols) return;
+    const int s = blockIdx.y;
+    const int64_t per = (rows + nsplit - 1) / nsplit;
+    const int64_t r0 = s * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+        float v0 = x[r * ldx + c], v1 = x[(r + 1) * ldx + c], v2 = x[(r + 2) * ldx + c], v3 = x[(r + 3) * ldx + c];
+        if (apply_log) { v0 = log1p_count(v0); v1 = log1p_count(v1); v2 = log1p_count(v2); v3 = log1p_count(v3); }
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; r < r1; ++r) a0 += apply_log ? log1p_count(x[r * ldx + c]) : x[r * ldx + c];
+    part[(int64_t)s * cols + c] = (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void col_mean_stage2(const float* __restrict__ part, int nsplit, int64_t cols, float inv_rows,
+                                                       float* __restrict__ out) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += part[(int64_t)s * cols + c];
+    out[c] = a * inv_rows;
+}
+
+// out[n] = bias[n] + sum_k W[n][k] c[k]: one workgroup per output row, fp32, 16-byte loads where the row allows
+__global__ __launch_bounds__(256) void gemv_bias_kernel(const float* __restrict__ W, int64_t ldw, int64_t N, int64_t K,
+                                                        const float* __restrict__ c, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int vec) {
+    __shared__ float red[32];
+    const int64_t n = blockIdx.x;
+    const float* w = W + n * ldw;
+    float a = 0.f;
+    if (vec) {
+        const int64_t kv = K >> 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = threadIdx.x; i < kv; i += 256)
+            acc += reinterpret_cast<const f32x4*>(w)[i] * reinterpret_cast<const f32x4*>(c)[i];
+        a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } else {
+        for (int64_t k = threadIdx.x; k < K; k += 256) a += w[k] * c[k];
+    }
+    a = block_sum<256>(a, red);
+    if (threadIdx.x == 0) out[n] = a + (bias ? bias[n] : 0.f);
+}
+
+// G[n][k] += r[n] * c[k]
+__global__ __launch_bounds__(256) void rank1_add_kernel(float* __restrict__ g, int64_t ldg, int64_t N, int64_t K,
+                                                        const float* __restrict__ r, const float* __restrict__ c, int vec) {
+    if (vec) {
+        const int64_t kv = K >> 2, total = N * kv;
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int64_t n = i / kv, k = (i - n * kv) << 2;
+            f32x4* p = reinterpret_cast<f32x4*>(g + n * ldg + k);
+            *p = *p + r[n] * *reinterpret_cast<const f32x4*>(c + k);
+        }
+    } else {
+        const int64_t total = N * K;
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int64_t n = i / K, k = i - n * K;
+            g[n * ldg + k] += r[n] * c[k];
+        }
+    }
 }
 
 }  // namespace c2
@@ -894,18 +1001,21 @@ extern "C" int c2_version(void) { return 1; }
 extern "C" size_t c2_reduce_ws(void) { return kReduceWsFloats; }
 
 extern "C" int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* out, int out_dtype,
-                             int64_t ldo, int apply_log, void* stream) {
+                             int64_t ldo, int apply_log, const float* center, void* stream) {
     C2_CHECK(x && out, "null pointer");
-    C2_CHECK(out_dtype == C2_F32 || out_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(out_dtype == C2_F32 || out_dtype == C2_BF16 || out_dtype == C2_F16, "bad dtype");
     C2_CHECK(ldx >= cols && ldo >= cols && rows >= 0 && cols >= 0, "bad shape");
     if (rows == 0 || cols == 0) return 0;
-    const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+    const bool vec = (cols % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out) &&
+                     (!center || aligned16(center));
     const int grid = grid_for(rows * cols / (vec ? 4 : 1));
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(TO, V) \
-    hipLaunchKernelGGL((prep_input_kernel<TO, V>), dim3(grid), dim3(256), 0, st, x, rows, cols, ldx, (TO*)out, ldo, apply_log)
+    hipLaunchKernelGGL((prep_input_kernel<TO, V>), dim3(grid), dim3(256), 0, st, x, rows, cols, ldx, (TO*)out, ldo, apply_log, center)
     if (out_dtype == C2_F32) {
         if (vec) LAUNCH(float, true); else LAUNCH(float, false);
+    } else if (out_dtype == C2_F16) {
+        if (vec) LAUNCH(f16_t, true); else LAUNCH(f16_t, false);
     } else {
         if (vec) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false);
     }
@@ -1134,8 +1244,11 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
                               float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
                               int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
                               const float* rowconst, float* rowconst_out, int32_t* idx32_out, int64_t idx32_len,
-                              void* stream) {
+                              const float* center, void* xin2_out, int64_t ldxin2, void* stream) {
     C2_CHECK(X && idx, "null pointer");
+    C2_CHECK(!center || xin_out || xin2_out, "center given without xin_out");
+    C2_CHECK(!xin2_out || ldxin2 >= G, "ldxin2 too small");
+    C2_CHECK(!xin_out || xin_dtype == C2_F32 || xin_dtype == C2_BF16 || xin_dtype == C2_F16, "bad xin dtype");
     C2_CHECK(!rowconst || rowconst_out, "rowconst_out missing");
     C2_CHECK(!idx32_out || idx32_len >= n, "idx32_out shorter than the batch");
     C2_CHECK(!sizefactor || sf_out, "sf_out missing");
@@ -1143,18 +1256,26 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
     C2_CHECK(!classes || classes_out, "classes_out missing");
     C2_CHECK(!xin_out || ldxin >= G, "ldxin too small");
     if (n == 0 || G == 0) return 0;
-    const int vec_ok = (G % 4 == 0) && aligned16(X) && (!x_out || aligned16(x_out)) &&
+    const int vec_ok = (G % 4 == 0) && aligned16(X) && (!x_out || aligned16(x_out)) && (!center || aligned16(center)) &&
                        (!(goodloc && goodloc_out) || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0));
     const int vec_xin = xin_out && aligned16(xin_out) && (ldxin % 8 == 0);
+    const int vec_xin2 = xin2_out && aligned16(xin2_out) && (ldxin2 % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (xin_out && xin_dtype == C2_BF16)
+    if (xin_out && xin_dtype == C2_F16)
+        hipLaunchKernelGGL((gather_rows_kernel<f16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+                           cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
+                           (f16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len,
+                           center, (bf16_t*)xin2_out, ldxin2, vec_xin2);
+    else if (xin_out && xin_dtype == C2_BF16)
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len);
+                           (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
+                           (bf16_t*)xin2_out, ldxin2, vec_xin2);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
-                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len);
+                           (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
+                           (bf16_t*)xin2_out, ldxin2, vec_xin2);
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -1235,13 +1356,14 @@ extern "C" int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4
 }
 
 extern "C" int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev,
-                                    uint64_t advance, void* stream) {
+                                    uint64_t lead, uint64_t advance, void* stream) {
     C2_CHECK(out && offset_dev && n >= 0 && aligned16(out), "out must be a 16-byte aligned buffer");
     C2_CHECK(p_drop >= 0.f && p_drop < 1.f, "bad dropout rate");
     if (n > 0) {
         const unsigned thresh8 = (unsigned)lrintf(p_drop * 256.f);
         hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, out, n,
-                           thresh8, (unsigned long long)seed, (const unsigned long long*)offset_dev);
+                           thresh8, (unsigned long long)seed, (const unsigned long long*)offset_dev,
+                           (unsigned long long)lead);
     }
     hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)offset_dev,
                        (unsigned long long)advance);
@@ -1322,5 +1444,61 @@ extern "C" int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream
     if (n == 0) return 0;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_cast_f16(const float* src, void* dst, int64_t n, void* stream) {
+    C2_CHECK(src && dst && n >= 0, "bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (f16_t*)dst, n);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t c2_col_mean_ws(int64_t rows, int64_t cols) {
+    const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(64, rows / 64));
+    return (size_t)(ns * cols);
+}
+
+extern "C" int c2_col_mean(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, float* out, float* ws,
+                           void* stream) {
+    C2_CHECK(rows >= 0 && cols >= 0, "negative size");
+    if (cols == 0) return 0;
+    C2_CHECK(out && ws, "null pointer");
+    C2_CHECK(rows > 0 && x && ldx >= cols, "bad arguments (the mean of no rows is undefined)");
+    const int ns = (int)std::max<int64_t>(1, std::min<int64_t>(64, rows / 64));
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((cols + 255) / 256);
+    hipLaunchKernelGGL(col_mean_stage1, dim3(gx, ns), dim3(256), 0, st, x, ldx, rows, cols, apply_log, ns, ws);
+    hipLaunchKernelGGL(col_mean_stage2, dim3(gx), dim3(256), 0, st, (const float*)ws, ns, cols, 1.0f / (float)rows, out);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_gemv_bias(const float* W, int64_t ldw, int64_t N, int64_t K, const float* c, const float* bias, float* out,
+                            void* stream) {
+    C2_CHECK(N >= 0 && K >= 0, "negative size");
+    if (N == 0) return 0;
+    C2_CHECK(W && c && out && ldw >= K, "bad arguments");
+    const int vec = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W) && aligned16(c);
+    hipLaunchKernelGGL(gemv_bias_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, c, bias, out, vec);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_rank1_add(float* G, int64_t ldg, int64_t N, int64_t K, const float* r, const float* c, void* stream) {
+    C2_CHECK(N >= 0 && K >= 0, "negative size");
+    if (N == 0 || K == 0) return 0;
+    C2_CHECK(G && r && c && ldg >= K, "bad arguments");
+    const int vec = (K % 4 == 0) && (ldg % 4 == 0) && aligned16(G) && aligned16(c);
+    hipLaunchKernelGGL(rank1_add_kernel, dim3(grid_for(N * K / (vec ? 4 : 1))), dim3(256), 0, (hipStream_t)stream, G, ldg, N, K,
+                       r, c, vec);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+// (a forward that raised between its loss kernels and its combine call: forget the second stages it left pending)
+extern "C" int c2_drop_pending_sums(void) {
+    g_pending_sums.count = 0;
     return 0;
 }

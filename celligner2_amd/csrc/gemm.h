@@ -31,4 +31,9 @@ int launch_gemm_wide(int layout, int tile, const GemmArgs& a, int nslab, hipStre
 // Row-indexed instances (256x256 tile, bf16, layouts 0 and 2 only); 0 = launched, 3 = shape not supported.
 int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream);
 
+// The same kernels on IEEE half operands (gemm_wide_f16.hip; dtype C2_F16).
+int wide_tile_f16(int dtype, const GemmArgs& a);
+int launch_gemm_wide_f16(int layout, int tile, const GemmArgs& a, int nslab, hipStream_t stream);
+int launch_gemm_wide_rows_f16(int layout, const GemmArgs& a, int nslab, hipStream_t stream);
+
 }  // namespace c2

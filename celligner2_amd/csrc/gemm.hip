@@ -12,6 +12,8 @@
 // Split reductions write fp32 slabs (deterministic; the consumer kernel sums them).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace c2 {
@@ -28,6 +30,9 @@ struct Cfg<bf16_t> {
     static constexpr int S_RC = 72;   // [128][72] bf16: 144-B rows, ds_read_b128 conflict-free
     static constexpr int S_XC = 160;  // [64][160] bf16: 320-B rows, 4 k-rows hit 4 distinct 64-B bank groups
 };
+struct f16_tag {};  // tag: IEEE half operands (raw 16-bit words, staged like bf16; v_mfma_f32_32x32x16_f16)
+template <>
+struct Cfg<f16_tag> : Cfg<bf16_t> {};
 template <>
 struct Cfg<float> {
     typedef float GT;
@@ -218,7 +223,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        if constexpr (std::is_same<T, f16_tag>::value) {
+                            typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        }
             }
         } else if constexpr (Cfg<T>::NTILE == 2) {
             const bf16_t* aLo = ldsA + tile_elems<T, A_RC>();
@@ -317,10 +328,16 @@ static bool wide_enabled() {
 }
 
 static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream_t stream) {
-    const int BK = (dtype == C2_BF16 || dtype == C2_BF16X3P) ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
+    const int BK = (dtype == C2_BF16 || dtype == C2_BF16X3P || dtype == C2_F16) ? Cfg<bf16_t>::BK : Cfg<float>::BK;  // x3 shares the fp32 K tile
     int64_t per = (a.R + nslab - 1) / nslab;
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
+    if (dtype == C2_F16) {  // the half-precision twin of the LDS-DMA kernels, else the register-staged kernel
+        if (layout == 3) return 3;
+        const int wt16 = wide_enabled() ? wide_tile_f16(dtype, a) : 0;
+        if (wt16) return launch_gemm_wide_f16(layout, wt16, a, nslab, stream);
+        return gemm_layout<f16_tag>(layout, a, nslab, stream);
+    }
     const int wt = (wide_enabled() || dtype == C2_BF16X3P) ? wide_tile(dtype, a) : 0;
     if (layout == 3 && (wt != 256 || dtype != C2_BF16)) return 3;  // (XC, RC) exists on the 256x256 kernel only
     if (wt) return launch_gemm_wide(layout, wt, a, nslab, stream);
@@ -355,7 +372,7 @@ __global__ void sum_slabs_2d_kernel(const float* __restrict__ slabs, int nslab, 
 using namespace c2;
 
 static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) {
-    return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3 || dtype == C2_BF16X3P) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
+    return (dtype == C2_F32 || dtype == C2_BF16 || dtype == C2_F32X3 || dtype == C2_BF16X3P || dtype == C2_F16) && M >= 0 && N >= 0 && K >= 0 && nslab >= 1 && nslab <= 65535 &&
            M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
 
@@ -365,7 +382,7 @@ extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
     a.N = (int)std::min<int64_t>(N, 1 << 30);
     a.R = (int)std::min<int64_t>(R, 1 << 30);
     if (dtype == C2_BF16X3P) return wide_tile(dtype, a);
-    const int wt = wide_enabled() ? wide_tile(dtype, a) : 0;
+    const int wt = !wide_enabled() ? 0 : (dtype == C2_F16 ? wide_tile_f16(dtype, a) : wide_tile(dtype, a));
     return wt ? wt : 128;
 }
 
@@ -438,9 +455,10 @@ extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t 
 }
 
 extern "C" int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_rows, const int32_t* row_index, const void* W,
-                                  int64_t ldw, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
+                                  int64_t ldw, int dtype, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
                                   int64_t slab_stride, const float* bias, void* stream) {
-    C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
+    C2_CHECK(dtype == C2_BF16 || dtype == C2_F16, "row-indexed operands are bf16 or f16");
+    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad shape");
     C2_CHECK(A_full && row_index && W && Y, "null pointer");
     C2_CHECK(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
     C2_CHECK(a_rows >= 1 && a_rows * lda < (1ll << 31), "resident matrix too large for 32-bit element offsets");
@@ -450,7 +468,7 @@ extern "C" int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_row
     GemmArgs a{A_full, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr, row_index};
     int64_t per = (a.R + nslab - 1) / nslab;
     a.r_per_split = (int)((per + 63) / 64 * 64);
-    C2_CHECK(launch_gemm_wide_rows(0, a, nslab, (hipStream_t)stream) == 0,
+    C2_CHECK((dtype == C2_F16 ? launch_gemm_wide_rows_f16 : launch_gemm_wide_rows)(0, a, nslab, (hipStream_t)stream) == 0,
              "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): gather the rows instead");
     C2_LAUNCH_CHECK();
     return 0;

@@ -25,8 +25,32 @@
 
 #include "gemm.h"
 
+// This file is compiled twice: as it stands (bf16 operands), and through gemm_wide_f16.hip with C2_WIDE_F16 defined --
+// the same kernels on v_mfma_f32_*_f16 (IEEE half operands: 11 significant bits instead of 8 at the same matrix rate;
+// the encoder's first layer reads its input and weight that way in bf16 mode).  Nothing but the MFMA instruction depends
+// on the 2-byte format: LDS-DMA staging, transposing reads and the epilogue move 16-bit words.  The twin lives in
+// namespace c2::wide_f16 and exports wide_tile_f16 / launch_gemm_wide_f16 / launch_gemm_wide_rows_f16.
+#ifdef C2_WIDE_F16
+#define C2_WIDE_NS wide_f16
+#define C2_WIDE_DT C2_F16
+#define wide_tile wide_tile_f16
+#define launch_gemm_wide launch_gemm_wide_f16
+#define launch_gemm_wide_rows launch_gemm_wide_rows_f16
+#define c2_dbg_clk c2_dbg_clk_f16
+typedef __attribute__((ext_vector_type(8))) _Float16 c2_f16x8;
+#define C2_MFMA_32x32x16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c2_f16x8, a), __builtin_bit_cast(c2_f16x8, b), c, 0, 0, 0)
+#define C2_MFMA_16x16x32(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(c2_f16x8, a), __builtin_bit_cast(c2_f16x8, b), c, 0, 0, 0)
+#else
+#define C2_WIDE_NS wide
+#define C2_WIDE_DT C2_BF16
+#define C2_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define C2_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+
 namespace c2 {
-namespace wide {
+namespace C2_WIDE_NS {
 
 // Ablation builds only (-DC2_GEMM_DBG=1: no DMA, 2: no MFMA, 4 / 8: no A / B DMA in the steady loop); 0 in the product.
 #ifndef C2_GEMM_DBG
@@ -159,7 +183,7 @@ __device__ __forceinline__ void mma_step(const bf16x8 (&fa)[MI], const bf16x8 (&
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = C2_MFMA_32x32x16(fa[i], fb[j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -219,7 +243,7 @@ __device__ __forceinline__ void mma16_group(const bf16x8 (&fa)[4], const bf16x8 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i0 + i][j], 0, 0, 0);
+            acc[i0 + i][j] = C2_MFMA_16x16x32(fa[i], fb[j], acc[i0 + i][j]);
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -612,7 +636,7 @@ __device__ __forceinline__ void compute_tile16_64(const char* tA, const char* tB
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = C2_MFMA_16x16x32(fa[i], fb[j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -1011,9 +1035,9 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = C2_MFMA_32x32x16(ah[i], bh[j], acc[i][j]);
+                    acc[i][j] = C2_MFMA_32x32x16(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = C2_MFMA_32x32x16(al[i], bh[j], acc[i][j]);
                 }
         }
     }
@@ -1065,17 +1089,21 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
     }
 }
 
-}  // namespace wide
+}  // namespace C2_WIDE_NS
 
 #if C2_GEMM_DBG & 16
 extern "C" int c2_dbg_clk(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wide::g_clk), 32);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(C2_WIDE_NS::g_clk), 32);
 }
 #endif
 
 // 0 = not taken by this file; 256 / 128 = block-tile edge.
 int wide_tile(int dtype, const GemmArgs& a) {
+#ifdef C2_WIDE_F16
+    if (dtype != C2_F16) return 0;
+#else
     if (dtype != C2_BF16 && dtype != C2_BF16X3P) return 0;
+#endif
     if (!aligned16(a.A) || !aligned16(a.B) || (a.lda & 7) || (a.ldb & 7) || (a.R & 7)) return 0;
     if (dtype == C2_BF16X3P) {
         if (!aligned16(a.A_lo) || !aligned16(a.B_lo)) return 0;
@@ -1102,7 +1130,7 @@ static bool wide16_on(int layout) {
 }
 template <bool A_RC, bool B_RC, int IDX>
 static void launch_w16(const GemmArgs& a, int nslab, hipStream_t stream) {
-    using namespace wide;
+    using namespace C2_WIDE_NS;
     constexpr int LDS = 5 * 256 * BK * 2;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     static bool attr_set = false;
@@ -1116,7 +1144,7 @@ static void launch_w16(const GemmArgs& a, int nslab, hipStream_t stream) {
 
 template <int NW>
 static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
-    using namespace wide;
+    using namespace C2_WIDE_NS;
     if constexpr (NW == 8) {
         if (layout != 2 && wide16_on(layout)) {
             if (layout == 0) launch_w16<true, true, 0>(a, nslab, stream);
@@ -1154,8 +1182,8 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
 }
 
 int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
-    using namespace wide;
-    if (!a.rows || a.A_lo || (layout != 0 && layout != 2 && layout != 4) || wide_tile(C2_BF16, a) != 256) return 3;
+    using namespace C2_WIDE_NS;
+    if (!a.rows || a.A_lo || (layout != 0 && layout != 2 && layout != 4) || wide_tile(C2_WIDE_DT, a) != 256) return 3;
     if (layout != 2 && wide16_on(layout)) {
         if (layout == 0) launch_w16<true, true, 1>(a, nslab, stream);
         else launch_w16<true, false, 2>(a, nslab, stream);
@@ -1183,7 +1211,7 @@ int launch_gemm_wide_rows(int layout, const GemmArgs& a, int nslab, hipStream_t 
 
 template <int NWX>
 static void launch_x3_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
-    using namespace wide;
+    using namespace C2_WIDE_NS;
     constexpr int BX = 128;
     constexpr int LDS = 8 * BX * BK * 2;  // two stages of four 16 KB slots
     const int tiles_m = (a.M + BX - 1) / BX, tiles_n = (a.N + BX - 1) / BX;

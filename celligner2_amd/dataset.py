@@ -165,22 +165,38 @@ class DeviceDataset:
             c = self.__dict__["_rows4"] = (d[:, :self.G], m[:, :self.G])
         return c
 
-    def xin_resident(self, apply_log):
-        """[n, G] bf16: the encoder input of EVERY resident row (log(1+x) or x), converted once per dataset like the
-        size factors (3.8 GB for 100k x 19k of 288 GB).  A batch is then rows of this matrix, read in place by the
-        row-indexed GEMMs (c2_linear_fwd_rows / c2_linear_wgrad_rows): no per-step copy of the encoder input."""
+    def xin_center(self, apply_log):
+        """[G rounded up to 8] fp32 (pad zero): the per-gene mean of the encoder input log(1+x) (or x) over the resident
+        rows -- the vector c that bf16 mode subtracts from the encoder input before rounding it (include/c2mi.h,
+        c2_col_mean; the engine adds W c to the first layer's bias and (sum dh) (x) c to its weight gradient, so the layer
+        is unchanged).  Evaluated once per dataset, like the size factors."""
+        cache = self.__dict__.setdefault("_xin_center", {})
+        c = cache.get(bool(apply_log))
+        if c is None:
+            c = torch.zeros((self.G + 7) // 8 * 8, dtype=torch.float32, device=self.device)
+            ops.col_mean(self.data, bool(apply_log), out=c)
+            cache[bool(apply_log)] = c
+        return c
+
+    def xin_resident(self, apply_log, centered=True, dtype=torch.bfloat16):
+        """[n, G] bf16 (or IEEE half): the encoder input of EVERY resident row (log(1+x) or x, minus xin_center when `centered`),
+        converted once per dataset like the size factors (3.8 GB for 100k x 19k of 288 GB).  A batch is then rows of
+        this matrix, read in place by the row-indexed GEMMs (c2_linear_fwd_rows / c2_linear_wgrad_rows): no per-step
+        copy of the encoder input."""
         cache = self.__dict__.setdefault("_xin_res", {})
-        t = cache.get(bool(apply_log))
+        key = (bool(apply_log), bool(centered), dtype)
+        t = cache.get(key)
         if t is None:
             # (rows start on 16 bytes for the LDS-DMA GEMMs: a gene count that is not a multiple of 8 gets zero pad columns)
-            t = torch.zeros((self.n, (self.G + 7) // 8 * 8), dtype=torch.bfloat16, device=self.device)[:, :self.G]
+            t = torch.zeros((self.n, (self.G + 7) // 8 * 8), dtype=dtype, device=self.device)[:, :self.G]
+            c = self.xin_center(apply_log) if centered else None
             for s in range(0, self.n, 16384):
-                ops.prep_input(self.data[s:s + 16384], t[s:s + 16384], bool(apply_log))
-            cache[bool(apply_log)] = t
+                ops.prep_input(self.data[s:s + 16384], t[s:s + 16384], bool(apply_log), c)
+            cache[key] = t
         return t
 
     def gather(self, idx, xin_dtype=None, apply_log=False, bufs=None, nb_const=False, resident_rows=False,
-               resident_xin=False):
+               resident_xin=False, centered=False, xin2=False):
         """Batch dict for rows `idx` (int64 device tensor): the keys custom_collate would produce
         (trainers/celligner2/_utils.py:188-225) plus `xin`, the encoder input written by the same kernel.
 
@@ -188,11 +204,18 @@ class DeviceDataset:
         and the row index instead (`x_full`, `goodloc_full`, `row_index`) and the NB loss kernel reads the rows
         where they live -- the gather then moves 6 instead of 12 bytes per gene.
         resident_xin=True (with resident_rows, bf16 input, G * n < 2^31): the encoder input is not written either:
-        the batch carries `xin_full` (xin_resident) and `row_index32`, and only the per-row scalars are gathered."""
+        the batch carries `xin_full` (xin_resident) and `row_index32`, and only the per-row scalars are gathered.
+        centered=True (bf16 input): xin / xin_full hold the encoder input minus `xin_center`, which the batch carries.
+        xin2=True (xin_dtype float16): the batch also carries the bf16 twin of the encoder input, `xinb` / `xinb_full` (the
+        first layer's forward reads IEEE halves, its weight gradient bf16)."""
         n = idx.numel()
+        two_byte = xin_dtype in (torch.bfloat16, torch.float16)
+        xin2 = bool(xin2) and xin_dtype == torch.float16
+        centered = bool(centered) and two_byte
+        center = self.xin_center(apply_log) if centered else None
         resident_rows = resident_rows and xin_dtype is not None
-        resident_xin = (resident_xin and resident_rows and xin_dtype == torch.bfloat16 and self.n * self.G < 2 ** 31
-                        and n % 8 == 0)
+        resident_xin = (resident_xin and resident_rows and xin_dtype in (torch.bfloat16, torch.float16)
+                        and self.n * self.G < 2 ** 31 and n % 8 == 0)
         bufs = bufs if bufs is not None else {}
 
         def get(key, shape, dtype):
@@ -213,27 +236,35 @@ class DeviceDataset:
             cond_o = out["batch"] = get("batch", (n, self.conditions.shape[1]), torch.int64)
         if self.predictor_keys:
             cls_o = out["classes"] = get("classes", (n, self.predictors.shape[1]), torch.int64)
-        xin = idx32 = None
+        xin = xinb = idx32 = None
         if resident_xin:
-            out["xin_full"] = self.xin_resident(apply_log)
+            out["xin_full"] = self.xin_resident(apply_log, centered, xin_dtype)
+            if xin2:
+                out["xinb_full"] = self.xin_resident(apply_log, centered, torch.bfloat16)
             idx32 = out["row_index32"] = get("row_index32", ((n + 63) // 64 * 64,), torch.int32)
         elif xin_dtype is not None:
-            if xin_dtype == torch.bfloat16 and self.G % 8:  # (see xin_resident)
-                g8 = (self.G + 7) // 8 * 8
-                full = bufs.get("xin.padded")
-                if full is None or tuple(full.shape) != (n, g8):
-                    full = bufs["xin.padded"] = torch.zeros((n, g8), dtype=xin_dtype, device=self.device)
-                xin = out["xin"] = full[:, :self.G]
-            else:
-                xin = out["xin"] = get("xin", (n, self.G), xin_dtype)
+            def two_byte_rows(key, dtype):
+                if self.G % 8:  # (see xin_resident)
+                    g8 = (self.G + 7) // 8 * 8
+                    full = bufs.get(key + ".padded")
+                    if full is None or tuple(full.shape) != (n, g8) or full.dtype != dtype:
+                        full = bufs[key + ".padded"] = torch.zeros((n, g8), dtype=dtype, device=self.device)
+                    return full[:, :self.G]
+                return get(key, (n, self.G), dtype)
+
+            xin = out["xin"] = two_byte_rows("xin", xin_dtype) if two_byte else get("xin", (n, self.G), xin_dtype)
+            if xin2:
+                xinb = out["xinb"] = two_byte_rows("xinb", torch.bfloat16)
         rc = rc_o = None
         if nb_const:
             rc, rc_o = self.nb_row_const, get("lgx1", (n,), torch.float32)
             out["lgx1"] = rc_o
+        if centered:
+            out["xin_center"] = center
         ops.gather_rows(self.data, self.goodloc, self.size_factors, self.conditions if cond_o is not None else None,
                         self.predictors if cls_o is not None else None, idx, out.get("x"), out.get("goodloc"),
                         out["sizefactor"], cond_o, cls_o, xin, apply_log, rowconst=rc, rowconst_out=rc_o,
-                        idx32_out=idx32)
+                        idx32_out=idx32, center=center if xin is not None else None, xin2_out=xinb)
         return out
 
 

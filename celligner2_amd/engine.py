@@ -121,11 +121,32 @@ class StepEngine:
                 blk.gt = self.gemm_dtype(blk.w)
             for a, b in zip(chain[:-1], chain[1:]):
                 a.out_t = b.gt
+        # bf16 mode: a gene-width first layer reads its input CENTRED (minus a per-gene vector c), the centre's share W c
+        # goes into the bias in fp32 and (sum_b dh_b) (x) c into the weight gradient -- the same layer, but the operand that
+        # is rounded to bf16 no longer carries the per-gene level all cells share (include/c2mi.h, c2_col_mean)
+        self.center_input = self.enc[0].gt == torch.bfloat16
+        self._center = None
+        # ... and, when that input is log(1 + x) (bounded by 89: in IEEE half's range whatever the counts), the first layer's
+        # FORWARD reads input and weight as IEEE halves (C2_F16: 11 significant bits instead of bf16's 8, the same matrix
+        # rate).  Measured at 19 000 genes against the fp64 oracle (tests/test_benchwidth_oracle_gpu.py): the 2^-9 rounding
+        # of a bf16 encoder input put the latent heads' gradients at 1.8-3 %, beyond bf16 mode's 1e-2.  The layer's weight
+        # gradient keeps bf16 operands (dh is a gradient: range matters more than digits), so the input exists in both forms.
+        log_in = bool(cfg["applylog"]) and cfg["recon_loss"] != "mse"
+        self.fwd16 = torch.float16 if (self.center_input and log_in) else None
         self.enc[-1].out_t = self.gemm_dtype("encoder.mean_encoder.weight")  # feeds the mean / log-var heads
         self.dec[-1].out_t = self.head_t
         self.cls[-1].out_t = self.gemm_dtype("classifier.classifier.0.weight")
 
     WIDE = 2048
+
+    def input_spec(self):
+        """Keywords of DeviceDataset.gather that deliver the encoder input in the form this engine reads: operand dtype of
+        the first layer's forward (None: it reads x itself), centred or not, with or without the bf16 twin."""
+        dt = self.fwd16 or self.enc[0].gt
+        log_in = bool(self.cfg["applylog"]) and self.cfg["recon_loss"] != "mse"
+        if dt == F32 and not log_in:
+            dt = None
+        return dict(xin_dtype=dt, centered=self.center_input, xin2=self.fwd16 is not None)
 
     def gemm_dtype(self, wname):
         if self.T == F32:
@@ -274,6 +295,7 @@ class StepEngine:
         p = self.p[name]
         if self.gemm_dtype(name) == F32:
             return p.detach()
+        wdt = self.fwd16 if (self.fwd16 is not None and name == self.enc[0].w) else torch.bfloat16
         sh = self._shadow.get(name)
         if sh is None or sh.shape != p.shape:
             if p.dim() == 2 and (p.shape[0] % 8 or p.shape[1] % 8):
@@ -284,9 +306,9 @@ class StepEngine:
                 # rows up to the next multiple, so that the input gradient's reduction over the genes can run over the
                 # padded count (_dgrad); the [G, H] view stays contiguous and the Adam kernel keeps refreshing it.
                 r8, ldp = (p.shape[0] + 7) // 8 * 8, (p.shape[1] + 7) // 8 * 8
-                sh = torch.zeros((r8, ldp), dtype=torch.bfloat16, device=self.dev)[:p.shape[0], :p.shape[1]]
+                sh = torch.zeros((r8, ldp), dtype=wdt, device=self.dev)[:p.shape[0], :p.shape[1]]
             else:
-                sh = torch.empty(p.shape, dtype=torch.bfloat16, device=self.dev)
+                sh = torch.empty(p.shape, dtype=wdt, device=self.dev)
             self._shadow[name] = sh
             self._shadow_ver[name] = None
         if self._shadow_ver[name] != p._version:
@@ -592,6 +614,35 @@ class StepEngine:
             ops.sum_slabs_2d(slabs, g[:, cut:])
         return True
 
+    def _batch_center(self, x, log_in):
+        """Centre of a batch handed in as tensors: the per-gene mean of its own encoder input (any vector is exact; the
+        mean leaves the smallest operand).  [G rounded up to 8] fp32, pad zero."""
+        B, G = x.shape
+        c = self.buf("enc0.center", ((G + 7) // 8 * 8,), zero=True)
+        ops.col_mean(x, log_in, out=c, ws=self.buf("enc0.center.ws", (ops.col_mean_ws(B, G),)))
+        if self.exchange:
+            # ranks hold equal shares of the global batch: the mean of their means is the global batch's mean, so N ranks
+            # round the same operand values as one process on the whole batch
+            self.comm.allreduce_scalars(c)
+            ops.scale(c, self._inv_world(), c)
+        return c
+
+    def _inv_world(self):
+        c = self._ws.get("inv_world")
+        if c is None or c[0] != self.world_size:
+            c = self._ws["inv_world"] = (self.world_size, torch.full((1,), 1.0 / self.world_size, device=self.dev))
+        return c[1]
+
+    def _set_center(self, center):
+        """Adopt the centre c of this batch's encoder input (or None): the first layer's bias becomes b + W c (fp32, from the
+        master weight: the centre's share of the layer must not see the bf16 rounding of W)."""
+        self._center = center
+        if center is None:
+            return
+        blk = self.enc[0]
+        w = self.p[blk.w].detach()
+        ops.gemv_bias(w, center, self.p[blk.b].detach() if blk.b else None, self.buf("enc0.bias_eff", (w.shape[0],)))
+
     def _block_fwd(self, blk, a, cond, masks, train, save):
         B = a.shape[0] if not isinstance(a, tuple) else self._B
         y = self._linear_slabs(blk.name, a, blk.w, B)
@@ -603,6 +654,8 @@ class StepEngine:
         mask = masks.get(blk.drop_name) if (train and p > 0) else None
         planes = self._tail_planes(blk.name + ".act.pl", act)
         bias = self.p[blk.b].detach() if blk.b else None
+        if blk is self.enc[0] and self._center is not None:
+            bias = self._ws["enc0.bias_eff"]
         wc = self.p[blk.wc].detach() if blk.wc else None
         if blk.norm:
             self._bn_fwd(blk, y, bias, cond if blk.use_cond else None, wc, mask, p if mask is not None else 0.0, act,
@@ -667,15 +720,19 @@ class StepEngine:
             ops.epilogue_bwd(dact, mask, p if mask is not None else 0.0, self.cfg["use_ln"],
                              self._ws[blk.name + ".yhat"], self._ws[blk.name + ".rstd"], dh, extra=extra,
                              extra_scale=extra_scale, planes=planes)
-        if self.p[blk.w].requires_grad:
+        need_w = self.p[blk.w].requires_grad
+        if need_w:
             self._wgrad(dh, a_in, blk.w)
         need_b = blk.b is not None and self.p[blk.b].requires_grad
         need_c = blk.wc is not None and self.p[blk.wc].requires_grad
-        if need_b or need_c:
+        centred = blk is self.enc[0] and self._center is not None and need_w  # dW += (sum_b dh_b) (x) c
+        if need_b or need_c or centred:
             C = cond.shape[1] if need_c else 0
             ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
-            ops.bias_cond_grad(dh, cond if need_c else None, self.gbuf(blk.b) if need_b else None,
-                               self.gbuf(blk.wc) if need_c else None, ws)
+            db = self.gbuf(blk.b) if need_b else (self.buf("enc0.dhsum", (H,)) if centred else None)
+            ops.bias_cond_grad(dh, cond if need_c else None, db, self.gbuf(blk.wc) if need_c else None, ws)
+            if centred:
+                ops.rank1_add(self.grad[blk.w], db, self._center)
         if not need_da:
             return None
         K = self.p[blk.w].shape[1]
@@ -721,6 +778,9 @@ class StepEngine:
         ops.defer_loss_sums(True)
         try:
             return self._forward(batch, eps, masks, train, save, classes_given, True)
+        except BaseException:
+            ops.drop_pending_sums()  # the sums this forward left waiting must not reach a later combine launch
+            raise
         finally:
             ops.defer_loss_sums(False)
 
@@ -756,34 +816,55 @@ class StepEngine:
             self._build_arena()  # (sharded form: the parameters move into the flat buffer BEFORE anything reads them)
         log_in = cfg["applylog"] and cfg["recon_loss"] != "mse"
         xt = self.enc[0].gt
+        ft = self.fwd16 or xt  # operand dtype of the first layer's forward (its weight gradient reads `xt`)
         pre = batch.get("xin")  # already produced by the device-resident gather
         rows = None
+        wg_in = None  # what the first layer's weight gradient reads when that is not the forward's operand
         if pre is None and batch.get("xin_full") is not None:
             # the encoder input stays in the resident bf16 matrix: the first layer's GEMMs read it through the row index
             xf, r32 = batch["xin_full"], batch["row_index32"]
             H0 = self.p[self.enc[0].w].shape[0]
-            if not (xt == torch.bfloat16 and xf.dtype == torch.bfloat16 and B % 8 == 0
+            if self.fwd16 is not None:
+                xb = batch.get("xinb_full")
+                if xb is None or xb.dtype != xt or xb.shape != xf.shape:
+                    raise ValueError("an f16 xin_full needs its bf16 twin xinb_full (the weight gradient's operand)")
+                wg_in = (xb, r32)
+            if not (xt == torch.bfloat16 and xf.dtype == ft and B % 8 == 0
                     and ops.gemm_tile(xt, B, H0, G) == 256 and ops.gemm_tile(xt, H0, G, B) == 256):
                 raise ValueError("xin_full / row_index32 need bf16 mode and a first layer the 256x256 GEMM takes; "
                                  "gather the encoder input instead (DeviceDataset.gather(resident_xin=False))")
             rows = (xf, r32)
             xin = None
-        elif pre is not None and pre.dtype == xt:
+            center = batch.get("xin_center")
+        elif pre is not None and pre.dtype == ft:
             xin = pre
+            center = batch.get("xin_center")
+            if self.fwd16 is not None:
+                wg_in = batch.get("xinb")
+                if wg_in is None or wg_in.dtype != xt or wg_in.shape != xin.shape:
+                    raise ValueError("an f16 xin needs its bf16 twin xinb (the weight gradient's operand)")
         elif x is None:
             raise ValueError("a batch without x needs xin in the encoder's operand dtype")
         elif log_in or xt != F32:
-            xin = self.abuf("xin", (B, G), xt)
-            ops.prep_input(x, xin, log_in)
+            xin = self.abuf("xin", (B, G), ft)
+            center = self._batch_center(x, log_in) if self.center_input else None
+            ops.prep_input(x, xin, log_in, center)
+            if self.fwd16 is not None and save:
+                wg_in = self.abuf("xinb", (B, G), xt)
+                ops.prep_input(x, wg_in, log_in, center)
         else:
             xin = x
+            center = None
         self._xin = xin
+        self._set_center(center)
         # ---- encoder
         a = xin if rows is None else rows
         self._enc_in = []
         for blk in self.enc:
             self._enc_in.append(a)
             a = self._block_fwd(blk, a, cond, masks, train, save)
+        if wg_in is not None:
+            self._enc_in[0] = wg_in
         self._henc = a
         L = cfg["latent"]
         mu, lv = self._heads_fwd(a, B, L)
@@ -1061,11 +1142,15 @@ class StepEngine:
         """Forward-only encoder: returns (mu, logvar, z) fp32 (celligner2.py:376-409)."""
         cfg = self.cfg
         B, G = x.shape
+        center = None
         if cfg["applylog"] or self.enc[0].gt != F32:
-            xin = self.abuf("xin", (B, G), self.enc[0].gt)
-            ops.prep_input(x, xin, cfg["applylog"])  # get_latent applies the log for every recon loss (:398-399)
+            # (an MSE model trains on x but get_latent takes log(1 + x), celligner2.py:398-399: its engine has no f16 form)
+            xin = self.abuf("xin", (B, G), self.fwd16 or self.enc[0].gt)
+            center = self._batch_center(x, cfg["applylog"]) if self.center_input else None
+            ops.prep_input(x, xin, cfg["applylog"], center)  # get_latent applies the log for every recon loss (:398-399)
         else:
             xin = x
+        self._set_center(center)
         self._aplanes = {}
         a = xin
         for blk in self.enc:

@@ -458,11 +458,14 @@ class Celligner2(nn.Module):
                     self.__dict__["_mask_seed"] = torch.initial_seed()
                     self.__dict__["_mask_offset"] = 0
                 ctr = self.__dict__.get("_mask_counter")
-                if ctr is not None and W == 1:
+                if ctr is not None:
+                    # (data-parallel: the counter holds the same value on every rank; rank r reads its stretch of the step's
+                    # range through the lead, exactly the host-counter form below)
                     if ctr is False or ctr.device != device:
                         ctr = self.__dict__["_mask_counter"] = torch.tensor(
                             [self.__dict__["_mask_offset"]], dtype=torch.int64, device=device)
-                    ops.dropout_masks_dev(flat, self.dr_rate, self.__dict__["_mask_seed"], ctr, total // 16)
+                    ops.dropout_masks_dev(flat, self.dr_rate, self.__dict__["_mask_seed"], ctr, W * (total // 16),
+                                          lead=r * (total // 16))
                 else:
                     ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"],
                                       self.__dict__["_mask_offset"] + r * (total // 16))
@@ -476,11 +479,13 @@ class Celligner2(nn.Module):
     # ------------------------------------------------------------------ the reference's API
     def forward(self, x=None, batch=None, sizefactor=None, classes=None, weight=None, goodloc=None,
                 main_dataset=None, xin=None, lgx1=None, x_full=None, goodloc_full=None, row_index=None,
-                xin_full=None, row_index32=None):
+                xin_full=None, row_index32=None, xin_center=None, xinb=None, xinb_full=None):
         """The reference's forward (celligner2.py:259-374).  Extra keywords, all produced by DeviceDataset.gather:
         xin (encoder input already transformed), lgx1 (data-only NB term), and x_full / goodloc_full / row_index
         (the batch's counts are rows `row_index` of the resident matrices; x itself is then not needed), and
-        xin_full / row_index32 instead of xin (the encoder input is read in place from the resident bf16 matrix)."""
+        xin_full / row_index32 instead of xin (the encoder input is read in place from the resident bf16 matrix);
+        xin_center: the per-gene vector that was subtracted from xin / xin_full (bf16 mode's centred encoder input);
+        xinb / xinb_full: the bf16 twin of an IEEE-half xin / xin_full (the first layer's weight gradient reads it)."""
         if weight is not None:
             raise NotImplementedError("per-sample `weight` (the reference passes it to the classifier's BCE, "
                                       "losses.py:318-333; its loader always delivers None) is outside the path")
@@ -517,6 +522,14 @@ class Celligner2(nn.Module):
             if row_index32 is None:
                 raise ValueError("xin_full needs row_index32")
             bt["xin_full"], bt["row_index32"] = xin_full, row_index32
+        if xinb is not None:
+            bt["xinb"] = xinb
+        if xinb_full is not None:
+            bt["xinb_full"] = xinb_full
+        if xin_center is not None:
+            if xin is None and xin_full is None:
+                raise ValueError("xin_center describes xin / xin_full")
+            bt["xin_center"] = xin_center
         if lgx1 is not None:  # per-row sum of goodloc*lgamma(x+1), precomputed by a resident dataset
             bt["lgx1"] = lgx1.float().contiguous()
         eps, masks = self._draw_noise(B, classes is not None, dev)

@@ -93,11 +93,54 @@ def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False
     return max(1, n)
 
 
-def prep_input(x, out, apply_log):
-    L.require_gpu(x, out)
+def prep_input(x, out, apply_log, center=None):
+    """out = log(1 + x) or x, minus center [cols] per column when given (the centred encoder input of bf16 mode)."""
+    L.require_gpu(x, out, center)
+    if center is not None:
+        assert center.dtype == torch.float32 and center.is_contiguous() and center.numel() >= x.shape[1]
     check(lib.c2_prep_input(ptr(x), x.shape[0], x.shape[1], _row_major(x, "x"), ptr(out), dt_code(out.dtype),
-                            _row_major(out, "out"), int(apply_log), stream()))
+                            _row_major(out, "out"), int(apply_log), ptr(center), stream()))
     return out
+
+
+def col_mean(x, apply_log, out=None, ws=None):
+    """[cols] fp32: mean over the rows of log(1 + x) (or x) -- the centre of the encoder input (c2mi.h, c2_col_mean)."""
+    L.require_gpu(x)
+    rows, cols = x.shape
+    assert x.dtype == torch.float32 and rows > 0
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    need = int(lib.c2_col_mean_ws(rows, cols))
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= cols and ws.numel() >= need
+    check(lib.c2_col_mean(ptr(x), _row_major(x, "x"), rows, cols, int(apply_log), ptr(out), ptr(ws), stream()))
+    return out
+
+
+def col_mean_ws(rows, cols):
+    return int(lib.c2_col_mean_ws(rows, cols))
+
+
+def gemv_bias(w, c, bias, out):
+    """out[n] = bias[n] + sum_k w[n, k] c[k] (fp32): the first layer's bias with the centre's contribution W c folded in."""
+    L.require_gpu(w, c, out)
+    N, K = w.shape
+    assert w.dtype == torch.float32 and c.dtype == torch.float32 and out.dtype == torch.float32
+    assert c.is_contiguous() and c.numel() >= K and out.is_contiguous() and out.numel() == N
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
+    check(lib.c2_gemv_bias(ptr(w), _row_major(w, "w"), N, K, ptr(c), ptr(bias), ptr(out), stream()))
+    return out
+
+
+def rank1_add(g, r, c):
+    """g[n, k] += r[n] * c[k] (fp32): the centre's term (sum_b dh_b) (x) c of the first layer's weight gradient."""
+    L.require_gpu(g, r, c)
+    N, K = g.shape
+    assert g.dtype == torch.float32 and r.dtype == torch.float32 and c.dtype == torch.float32
+    assert r.is_contiguous() and r.numel() == N and c.is_contiguous() and c.numel() >= K
+    check(lib.c2_rank1_add(ptr(g), _row_major(g, "g"), N, K, ptr(r), ptr(c), stream()))
+    return g
 
 
 def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
@@ -116,23 +159,23 @@ def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
     return y
 
 
-def _rows_arg(a_full, rows, need):
-    assert a_full.dtype == torch.bfloat16 and a_full.dim() == 2 and a_full.stride(1) == 1
+def _rows_arg(a_full, rows, need, dtypes=(torch.bfloat16,)):
+    assert a_full.dtype in dtypes and a_full.dim() == 2 and a_full.stride(1) == 1
     assert rows.dtype == torch.int32 and rows.is_contiguous() and rows.numel() >= need
 
 
 def linear_fwd_rows(a_full, rows, M, w, y, bias=None, nslab=1):
-    """y[s] = a_full[rows[:M]] @ w.T (+bias): the batch is read in place from the resident bf16 matrix."""
+    """y[s] = a_full[rows[:M]] @ w.T (+bias): the batch is read in place from the resident bf16 (or f16) matrix."""
     L.require_gpu(a_full, rows, w, y)
-    _rows_arg(a_full, rows, M)
+    _rows_arg(a_full, rows, M, (torch.bfloat16, torch.float16))
     N, K = w.shape
-    assert w.dtype == torch.bfloat16 and a_full.shape[1] == K and y.dtype == torch.float32
+    assert w.dtype == a_full.dtype and a_full.shape[1] == K and y.dtype == torch.float32
     y2 = y if y.dim() == 2 else y[0]
     assert tuple(y2.shape) == (M, N) and ((y.dim() == 3 and y.shape[0] == nslab) or nslab == 1)
     ss = y.stride(0) if y.dim() == 3 else 0
     with _GemmTimer(M, N, K):
         check(lib.c2_linear_fwd_rows(ptr(a_full), a_full.stride(0), a_full.shape[0], ptr(rows), ptr(w), _row_major(w, "w"),
-                                     M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
+                                     dt_code(w.dtype), M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss, ptr(bias), stream()))
     return y
 
 
@@ -543,12 +586,16 @@ def _adam_table(entries):
         if isinstance(sh, tuple):  # (hi, lo) planes given separately (rows of a stacked operand)
             sh, lo = sh
             assert lo.dtype == torch.bfloat16 and lo.is_contiguous() and lo.numel() == p.numel()
-        if sh is not None:
+        f16 = 0
+        if sh is not None and sh.dtype == torch.float16:  # an IEEE-half operand copy (the encoder's first layer)
+            assert lo is None and sh.is_contiguous() and sh.numel() == p.numel()
+            f16 = 1
+        elif sh is not None:
             assert sh.dtype == torch.bfloat16 and sh.is_contiguous()
             if lo is None and sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
                 sh, lo = sh[0], sh[1]
             assert sh.numel() == p.numel()
-        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo))
+        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo), f16)
     return arr, n
 
 
@@ -593,15 +640,22 @@ def transpose_bf16(src, dst):
 
 
 def cast_bf16(src, dst):
+    """fp32 -> bf16 (or IEEE half, by dst's dtype) copy of a contiguous tensor."""
     L.require_gpu(src, dst)
-    assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
-    check(lib.c2_cast_bf16(ptr(src), ptr(dst), src.numel(), stream()))
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    assert dst.dtype in (torch.bfloat16, torch.float16)
+    fn = lib.c2_cast_bf16 if dst.dtype == torch.bfloat16 else lib.c2_cast_f16
+    check(fn(ptr(src), ptr(dst), src.numel(), stream()))
     return dst
 
 
 def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, sf_out, cond_out, classes_out, xin_out,
-                apply_log, rowconst=None, rowconst_out=None, idx32_out=None):
-    L.require_gpu(X, idx, x_out)
+                apply_log, rowconst=None, rowconst_out=None, idx32_out=None, center=None, xin2_out=None):
+    L.require_gpu(X, idx, x_out, center, xin2_out)
+    if xin2_out is not None:
+        assert xin2_out.dtype == torch.bfloat16 and xin2_out.dim() == 2 and xin2_out.stride(1) == 1
+    if center is not None:
+        assert center.dtype == torch.float32 and center.is_contiguous() and center.numel() >= X.shape[1]
     if idx32_out is not None:
         assert idx32_out.dtype == torch.int32 and idx32_out.is_contiguous() and idx32_out.numel() >= idx.numel()
     G = X.shape[1]
@@ -614,12 +668,16 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
                              dt_code(xin_out.dtype) if xin_out is not None else 0,
                              xin_out.stride(0) if xin_out is not None else 0, int(apply_log), ptr(rowconst),
                              ptr(rowconst_out), ptr(idx32_out), idx32_out.numel() if idx32_out is not None else 0,
-                             stream()))
+                             ptr(center), ptr(xin2_out), xin2_out.stride(0) if xin2_out is not None else 0, stream()))
 
 
 def defer_loss_sums(on):
     """While on, the loss entry points leave their second-stage sums to the next combine_losses[_dev] (one launch)."""
     return bool(lib.c2_defer_loss_sums(1 if on else 0))
+
+
+def drop_pending_sums():
+    lib.c2_drop_pending_sums()
 
 
 def combine_losses(losses4, weights, out6):
@@ -681,14 +739,14 @@ def dropout_masks(out, p_drop, seed, offset):
     return out
 
 
-def dropout_masks_dev(out, p_drop, seed, offset_dev, advance):
-    """dropout_masks with the counter offset in device memory (int64 [1], read as uint64); it is advanced by `advance`
-    after the masks are drawn."""
+def dropout_masks_dev(out, p_drop, seed, offset_dev, advance, lead=0):
+    """dropout_masks with the counter offset in device memory (int64 [1], read as uint64): masks from *offset_dev + lead;
+    the counter is advanced by `advance` after the masks are drawn."""
     L.require_gpu(out, offset_dev)
     assert out.dtype == torch.uint8 and out.is_contiguous()
     assert offset_dev.dtype == torch.int64 and offset_dev.numel() == 1
     check(lib.c2_dropout_masks_dev(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), ptr(offset_dev),
-                                   int(advance), stream()))
+                                   int(lead), int(advance), stream()))
     return out
 
 
@@ -696,7 +754,7 @@ def decoder_output(logits, mode):
     """Softmax over the genes ("softmax") or ReLU ("relu") of the decoder's output layer, a new [B, G] fp32 tensor
     (reconstructLatent, celligner2.py:411-420)."""
     L.require_gpu(logits)
-    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and (logits.stride(1) == 1 or logits.numel() == 0)
     out = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
     check(lib.c2_decoder_output(ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1],
                                 {"softmax": 0, "relu": 1}[mode], ptr(out), out.stride(0), stream()))

@@ -21,8 +21,6 @@ class FusedAdam(torch.optim.Optimizer):
                  shadow_lookup=None, grad_sync=None, on_updated=None, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
         super().__init__(params, defaults)
-        if capturable and grad_sync is not None:
-            raise ValueError("a capturable step has no gradient exchange: one process, one GPU")
         self.capturable = bool(capturable)
         self._last = None  # (touched, refreshed) parameters of the latest step, for replayed()
         self._dev = {}     # id(group) -> device-resident step state
@@ -77,6 +75,17 @@ class FusedAdam(torch.optim.Optimizer):
                 self.state[p]["step"] += 1
             self._publish(touched, refreshed)
 
+    def step_counts(self):
+        """Host-side step counts (per tensor, per group's device state): what a capture attempt that fails must put back."""
+        return ([(p, self.state[p]["step"]) for g in self.param_groups for p in g["params"] if len(self.state[p])],
+                [(id(g), self._dev[id(g)]["step"]) for g in self.param_groups if id(g) in self._dev])
+
+    def restore_step_counts(self, saved):
+        for p, n in saved[0]:
+            self.state[p]["step"] = n
+        for gid, n in saved[1]:
+            self._dev[gid]["step"] = n
+
     def captured(self):
         """Call after a step() that ran under stream capture: its launches were recorded, not executed, so the step
         counts it advanced on the host are taken back (the first replay performs that step)."""
@@ -101,23 +110,24 @@ class FusedAdam(torch.optim.Optimizer):
             if not torch.cuda.is_current_stream_capturing():
                 self.sync_hyper()
             ops.adam_prepare(ds["state"], ds["block"])
-            ops.adam_step_dev(entries, ds["block"])
             ds["step"] = step_t
-            return
+            run = lambda part: ops.adam_step_dev(part, ds["block"])  # noqa: E731
+        else:
+            hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
+                     group.get("clip_value", 0.0), step_t)
+            run = lambda part: ops.adam_step(part, *hyper)  # noqa: E731
         if self._sharded():  # this rank updates only the elements whose reduced gradient it received
             entries = self._grad_sync.owned_parts(entries)
         rng = self._grad_sync.deferred_range() if self._grad_sync is not None else None
-        hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
-                 group.get("clip_value", 0.0), step_t)
         if rng is not None:
             late = [e for e in entries if rng[0] <= e[1].data_ptr() < rng[1]]
             early = [e for e in entries if not (rng[0] <= e[1].data_ptr() < rng[1])]
             if early:
-                ops.adam_step(early, *hyper)
+                run(early)
             self._grad_sync.wait_deferred()
             entries = late
         if entries:
-            ops.adam_step(entries, *hyper)
+            run(entries)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -228,6 +228,11 @@ class DataParallelStep:
         for ev, _, _ in pend:
             torch.cuda.current_stream().wait_event(ev)
 
+    def forget_pending(self):
+        """Drop the records of exchanges that were only recorded into a stream capture that has been abandoned."""
+        self._pending = []
+        self._deferred = None
+
     def deferred_range(self):
         return None if self._deferred is None else self._deferred[1:]
 

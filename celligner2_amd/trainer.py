@@ -12,10 +12,13 @@ What is different underneath: the dataset is resident in HBM and a batch is gath
 kernel); per-iteration loss scalars stay on the device and are averaged once per epoch (`log_sync="epoch"`) instead of
 six `.item()` syncs per step (`log_sync="step"` reproduces the reference's per-step floats and error timing).
 
-`graph=True` (one GPU, rng="device"): after two ordinary steps the whole iteration -- gather of the batch's rows,
+`graph=True` (rng="device"): after two ordinary steps the whole iteration -- gather of the batch's rows,
 forward, backward, Adam -- is captured once as a HIP graph and every further full-size batch is ONE graph launch
 (`_StepGraph`); what changes between steps (row indices, KL weight, learning rate, step count, dropout counter, loss
-sums) lives in device memory.  Short last batches and validation run the ordinary way.
+sums) lives in device memory.  Short last batches and validation run the ordinary way.  With `world` (one process per
+GPU over RCCL) the captured iteration includes the collectives -- latent all-gather, bucket reduce-scatter / all-reduce
+on the side stream, sharded Adam, parameter all-gather: RCCL's calls are stream-ordered and capturable, so the
+data-parallel step costs the host what the single-GPU step costs (one graph launch).
 """
 from __future__ import annotations
 
@@ -118,7 +121,9 @@ class _Loader:
     batch loses its last `len % world_size` rows and a last batch with fewer rows than ranks is skipped."""
 
     def __init__(self, dataset, batch_size, weights=None, num_samples=None, rng="reference", xin_dtype=None,
-                 apply_log=False, world=None, nb_const=False, resident_xin=None):
+                 apply_log=False, world=None, nb_const=False, resident_xin=None, centered=False, xin2=False):
+        self.centered = centered  # bf16 encoder input minus the dataset's per-gene mean (DeviceDataset.xin_center)
+        self.xin2 = xin2          # an IEEE-half encoder input travels with its bf16 twin (DeviceDataset.gather)
         self.nb_const = nb_const  # deliver the data-only NB term (sum goodloc*lgamma(x+1)) with every batch
         # callable(batch rows) -> bool: leave the encoder input in the dataset's resident bf16 matrix (read in place by the
         # row-indexed first-layer GEMMs) instead of writing a per-batch copy
@@ -126,6 +131,8 @@ class _Loader:
         self.ds, self.bs, self.weights, self.num_samples, self.rng = dataset, batch_size, weights, num_samples, rng
         self.xin_dtype, self.apply_log = xin_dtype, apply_log
         self.world = world
+        # rows of a full batch that this process handles: the batch, or this rank's share of the global batch
+        self.share = batch_size // world.world_size if (world is not None and world.world_size > 1) else batch_size
         self._bufs = {}
         self.static = False      # full-size batches are handed over as _StaticBatch (Trainer(graph=True))
         self.static_rows = None  # int64 [batch_size] on the device
@@ -133,7 +140,8 @@ class _Loader:
     def gather_static(self):
         n = self.static_rows.numel()
         return self.ds.gather(self.static_rows, self.xin_dtype, self.apply_log, self._bufs.setdefault(("static", n), {}),
-                              self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(n))
+                              self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(n),
+                              centered=self.centered, xin2=self.xin2)
 
     def __len__(self):
         n = self.num_samples if self.weights is not None else len(self.ds)
@@ -179,14 +187,15 @@ class _Loader:
                 if per == 0:
                     continue
                 sub = sub[self.world.rank * per:(self.world.rank + 1) * per]
-            if self.static and sub.numel() == self.bs:
+            if self.static and sub.numel() == self.share:
                 if self.static_rows is None:
-                    self.static_rows = torch.empty(self.bs, dtype=torch.int64, device=idx.device)
+                    self.static_rows = torch.empty(self.share, dtype=torch.int64, device=idx.device)
                 self.static_rows.copy_(sub)
-                yield _StaticBatch(self, self.bs)
+                yield _StaticBatch(self, self.share)
                 continue
             yield self.ds.gather(sub, self.xin_dtype, self.apply_log, self._bufs.setdefault(sub.numel(), {}),
-                                 self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(sub.numel()))
+                                 self.nb_const, resident_rows=self.nb_const, resident_xin=self.resident_xin(sub.numel()),
+                                 centered=self.centered, xin2=self.xin2)
 
 
 # keyword -> default of the options the reference pops from **kwargs (trainer.py:117-137), then the build-only ones
@@ -215,6 +224,7 @@ class _StepGraph:
 
     def __init__(self, trainer):
         self.trainer, self.graph, self.calls, self.count = trainer, None, 0, 0
+        self.refused = None  # why the capture was given up (data-parallel only), else None
         dev = trainer.device
         self.alpha = trainer.calc_alpha_coeff()
         self.weights = torch.tensor([1.0, self.alpha, 1.0, 1.0], dtype=torch.float32, device=dev)
@@ -247,22 +257,39 @@ class _StepGraph:
         if alpha != self.alpha:
             self.alpha = alpha
             self.weights[1:2].fill_(alpha)
-        if self.graph is None and self.calls >= self.WARMUP:
+        if self.graph is None and self.calls >= self.WARMUP and not self.refused:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             engine = t.model._engine()
             engine.recorded = self.scratch = []  # the graph owns every scratch tensor its kernels address
+            # (data-parallel: the process group's watchdog thread makes HIP calls of its own while this thread captures --
+            # only this thread's calls belong to the capture)
+            mode = {"capture_error_mode": "thread_local"} if t.world is not None else {}
+            steps = t.optimizer.step_counts()
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     self.total = self._iteration()
+            except Exception as exc:  # noqa: BLE001
+                if t.world is None:
+                    raise
+                # A collective library that refuses stream capture: nothing of the attempt has run.  Take the host-side
+                # bookkeeping of the attempt back and go on launching the step the ordinary way (recorded in
+                # `self.refused`, which bench.py reports).
+                self.refused = t.graph_refused = f"{type(exc).__name__}: {exc}"
+                t.optimizer.restore_step_counts(steps)
+                t.world.forget_pending()
+                torch.cuda.synchronize()
+                graph = None
             finally:
                 engine.recorded = None
-            t.optimizer.captured()  # recorded, not run: the replay below performs this step
-            self.graph, self.engine = graph, engine
+            if graph is not None:
+                t.optimizer.captured()  # recorded, not run: the replay below performs this step
+                self.graph, self.engine = graph, engine
         if self.graph is not None:
             t.optimizer.sync_hyper()
             self.graph.replay()
             t.optimizer.replayed()
+            t.graph_replays += 1
         else:
             self.total = self._iteration()
         self.calls += 1
@@ -320,10 +347,14 @@ class Trainer:
         self.model.to(self.device)
         self.model.rng_mode = self.rng
         self._graph = None
+        self.graph_replays, self.graph_refused = 0, None  # steps replayed from a captured graph; why a capture was given up
         if self.graph:
-            if self.world is not None or self.rng != "device" or self.log_sync != "epoch":
-                raise ValueError("graph=True replays the step on one GPU with device-side noise and per-epoch logs: "
-                                 "it needs world=None, rng='device' and log_sync='epoch'")
+            if self.rng != "device" or self.log_sync != "epoch":
+                raise ValueError("graph=True replays the step with device-side noise and per-epoch logs: "
+                                 "it needs rng='device' and log_sync='epoch'")
+            if self.world is not None and getattr(self.world, "_host_backend", False):
+                raise ValueError("graph=True with a data-parallel `world` needs the RCCL backend (\"nccl\"): a host-side "
+                                 "exchange (gloo) cannot be captured")
         if self.world is not None:
             self.world.attach_model(self.model)
         if staged is not None:  # DeviceDataset objects staged by the caller (adata may be None)
@@ -338,7 +369,8 @@ class Trainer:
     # ------------------------------------------------------------------ loaders (trainer.py:184-229)
     def _loader(self, data, batch_size, weights, n_samples):
         model = self.model
-        xin_dtype = model._engine().enc[0].gt
+        eng = model._engine()
+        xin_dtype = eng.fwd16 or eng.enc[0].gt
         log_in = model.applylog and model.recon_loss != "mse"
         if not log_in and xin_dtype == torch.float32:
             xin_dtype = None  # the encoder reads x itself
@@ -349,10 +381,11 @@ class Trainer:
 
         def in_place(n):  # both first-layer GEMMs (forward [n,H0] over G, weight gradient [H0,G] over n) on the 256x256 kernel
             from . import ops
-            return (nb and xin_dtype == torch.bfloat16 and n % 8 == 0
+            return (nb and xin_dtype in (torch.bfloat16, torch.float16) and n % 8 == 0
                     and ops.gemm_tile(torch.bfloat16, n, H0, G) == 256 and ops.gemm_tile(torch.bfloat16, H0, G, n) == 256)
 
-        return _Loader(data, batch_size, weights, n_samples, self.rng, xin_dtype, log_in, self.world, nb, in_place)
+        return _Loader(data, batch_size, weights, n_samples, self.rng, xin_dtype, log_in, self.world, nb, in_place,
+                       centered=eng.center_input, xin2=eng.fwd16 is not None)
 
     def initialize_loaders(self):
         n_train = len(self.train_data)

@@ -39,16 +39,37 @@ extern "C" {
  * count.  Staged by LDS-DMA like C2_BF16.  Needs 16-byte aligned planes, ld % 8 == 0 and a reduction length that
  * is a multiple of 8 and >= 64 (c2_gemm_tile returns 0 otherwise). */
 #define C2_BF16X3P 3
+/* IEEE half: operands of the GEMM entry points that take a dtype (staged and multiplied like C2_BF16, on
+ * v_mfma_f32_*_f16: 11 significant bits instead of 8 at the same matrix rate; no (XC, RC) form), and an output type of
+ * c2_prep_input / c2_gather_rows / c2_cast_f16.  bf16 mode reads the encoder's first-layer input (log(1 + x) <= 89, in
+ * range) and weight this way: at 19 000 genes the 2^-9 rounding of a bf16 encoder input carried the gradients of the
+ * latent heads past the 1e-2 bound. */
+#define C2_F16 4
 
 #define C2_MMD_MAX_PARTS 64 /* max distinct condition rows per batch for the MMD partition */
 
 const char* c2_last_error(void);
 int c2_version(void);
 
-/* x_log = log(1 + x) (celligner2/model/celligner2.py:269-274) or a plain copy/convert.
- * out dtype f32 or bf16.  rows x cols, ldx/ldo in elements. */
+/* x_log = log(1 + x) (celligner2/model/celligner2.py:269-274) or a plain copy/convert, minus center[col] when center is
+ * not NULL (see c2_col_mean).  out dtype f32 or bf16.  rows x cols, ldx/ldo in elements. */
 int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t ldx, void* out, int out_dtype,
-                  int64_t ldo, int apply_log, void* stream);
+                  int64_t ldo, int apply_log, const float* center, void* stream);
+
+/* Centred encoder input of bf16 mode.  The encoder's first Linear (modules.py:77-107, 281-290) computes
+ * h = t(x) W^T + b with t(x) = log(1 + x) or x (celligner2.py:269-274).  For any vector c [G]:
+ *   h  = (t(x) - c) W^T + (b + W c)                 c2_prep_input / c2_gather_rows (center) + c2_gemv_bias
+ *   dW = dh^T (t(x) - c) + (sum_b dh_b) (x) c       c2_linear_wgrad* + c2_rank1_add
+ * which is the same layer, but the operand rounded to bf16 is the centred part: expression values share a large
+ * per-gene level, and its 2^-9 rounding is what carried bf16 mode's gradient error past 1e-2 at 19 000 genes.
+ *   c2_col_mean:  out[col] = mean over rows of t(x)[row][col]   (ws: c2_col_mean_ws(rows, cols) floats)
+ *   c2_gemv_bias: out[n] = bias[n] + sum_k W[n][k] c[k]          (fp32; bias may be NULL)
+ *   c2_rank1_add: G[n][k] += r[n] * c[k] */
+size_t c2_col_mean_ws(int64_t rows, int64_t cols);
+int c2_col_mean(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, float* out, float* ws, void* stream);
+int c2_gemv_bias(const float* W, int64_t ldw, int64_t N, int64_t K, const float* c, const float* bias, float* out,
+                 void* stream);
+int c2_rank1_add(float* G, int64_t ldg, int64_t N, int64_t K, const float* r, const float* c, void* stream);
 
 /* nn.Linear forward without the bias/cond/norm tail (modules.py:100,126,296,314-315,443,469,481,617):
  *   Y[s][m][n] = sum_{k in split s} A[m][k] * W[n][k]      (+ bias[n] when bias != NULL; needs nslab == 1)
@@ -79,8 +100,8 @@ int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, in
  * row_index: int32, device; for the weight gradient it must be readable up to M rounded up to a multiple of 64
  * (pad with any valid row).  Other shapes: error -- gather the rows (c2_gather_rows) and use the plain entry points. */
 int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_rows, const int32_t* row_index, const void* W,
-                       int64_t ldw, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
-                       int64_t slab_stride, const float* bias, void* stream);
+                       int64_t ldw, int dtype /* C2_BF16 or C2_F16 */, int64_t M, int64_t N, int64_t K, float* Y,
+                       int64_t ldy, int nslab, int64_t slab_stride, const float* bias, void* stream);
 int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64_t lda, int64_t a_rows,
                          const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
                          int64_t slab_stride, const float* alpha_dev, void* stream);
@@ -272,6 +293,7 @@ typedef struct {
     int64_t n;
     void* shadow_lo;   /* NULL, or [n] bf16: the low plane lo = bf16(p - hi) next to shadow_bf16 = hi = bf16(p), the
                           C2_BF16X3P operand form of the fp32 weights of the narrow layers */
+    int32_t shadow_f16; /* non-zero: shadow_bf16 addresses [n] IEEE halves (C2_F16) instead of bf16; no shadow_lo */
 } c2_adam_tensor;
 int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
                  double weight_decay, double clip_value, int64_t step_t, void* stream);
@@ -293,8 +315,9 @@ int c2_adam_step_dev(const c2_adam_tensor* desc_host, int n_tensors, const void*
 /* dst[c][r] = src[r][c], bf16 (or any 2-byte type): the narrow operand of c2_linear_wgrad_bt / c2_linear_wgrad_rows_at. */
 int c2_transpose_bf16(const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* stream);
 
-/* fp32 -> bf16 copy (initial weight shadows), n elements. */
+/* fp32 -> bf16 copy (initial weight shadows), n elements; c2_cast_f16: fp32 -> IEEE half. */
 int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int c2_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 
 /* Device-resident dataset -> batch (replaces AnnotatedDataset.__getitem__ + custom_collate + .to(device),
  * dataset/celligner2/anndata.py:89-105, trainers/celligner2/_utils.py:188-225, trainer.py:274-275):
@@ -303,12 +326,16 @@ int c2_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * NULL when the consumer reads the resident rows itself (c2_recon_nb_fwd_bwd's row_index).  rowconst (may be NULL):
  * a second per-row fp32 scalar gathered like sizefactor (the dataset's c2_nb_row_const vector).  idx32_out (may be
  * NULL): idx as int32 [idx32_len >= n], entries past n filled with the last index -- the row index of
- * c2_linear_fwd_rows / c2_linear_wgrad_rows; with x_out, goodloc_out and xin_out all NULL nothing per gene is moved. */
+ * c2_linear_fwd_rows / c2_linear_wgrad_rows; with x_out, goodloc_out and xin_out all NULL nothing per gene is moved.
+ * center (may be NULL): subtracted from xin per gene (see c2_col_mean).  xin2_out (may be NULL): a second copy of xin,
+ * always bf16 [n, ldxin2] -- when xin is C2_F16 for the first layer's forward, its weight gradient (whose other operand,
+ * dh, is bf16) reads this one. */
 int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
                    const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n, float* x_out,
                    uint8_t* goodloc_out, float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out,
                    int xin_dtype, int64_t ldxin, int apply_log, const float* rowconst, float* rowconst_out,
-                   int32_t* idx32_out, int64_t idx32_len, void* stream);
+                   int32_t* idx32_out, int64_t idx32_len, const float* center, void* xin2_out, int64_t ldxin2,
+                   void* stream);
 
 /* ---- BatchNorm1d form of the layer tail (use_bn=True: modules.py:298-302, 405-413, 445-449, 557-566, 596-600;
  * nn.BatchNorm1d(affine=True), eps 1e-5, momentum 0.1).  The statistics run over the batch, so the tail is cut at
@@ -366,6 +393,9 @@ int c2_combine_losses(const float* losses4, float w0, float w1, float w2, float 
  * ends the mode (sums already waiting stay until the next combine).  Returns the previous setting.  No counterpart in
  * the reference (semisupervised.py:63-69 sums with torch ops): it removes five ~4.5 us graph nodes from a replayed step. */
 int c2_defer_loss_sums(int on);
+/* Forget the sums that wait on this thread: for a caller whose forward failed between a loss entry point and the combine
+ * call (their workspaces may be gone by the next combine). */
+int c2_drop_pending_sums(void);
 
 /* Its backward seed: out4[i] = w_i * g (g = *g_dev, or 1 when g_dev is NULL) -- the upstream gradients of the four
  * losses when the weighted total receives gradient g. */
@@ -377,10 +407,12 @@ int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float*
 int c2_combine_losses_dev(const float* losses4, const float* w_dev, float* out6, double* accum6, void* stream);
 int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* stream);
 
-/* c2_dropout_masks with the Philox counter offset in device memory: masks from *offset_dev, then *offset_dev += advance
- * (a second, one-thread launch), so that every replay of a captured step draws fresh masks. */
-int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev, uint64_t advance,
-                         void* stream);
+/* c2_dropout_masks with the Philox counter offset in device memory: masks from *offset_dev + lead, then
+ * *offset_dev += advance (a second, one-thread launch), so that every replay of a captured step draws fresh masks.
+ * lead: this rank's stretch of a step's counter range in a data-parallel run (rank x blocks per rank; advance is then
+ * world x blocks per rank, and every rank's counter holds the same value). */
+int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev, uint64_t lead,
+                         uint64_t advance, void* stream);
 
 /* Output activation of the decoder on the inference path -- Decoder.forward (celligner2/model/modules.py:467-482) as
  * Celligner2.reconstructLatent returns it (celligner2/model/celligner2.py:411-420): mode 0 = nn.Softmax(dim=-1) over the

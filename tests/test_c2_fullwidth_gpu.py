@@ -60,8 +60,8 @@ def test_small_batch_step_properties_at_19k_genes():
     eps = torch.randn(B, L, device=DEV, generator=g)
     m16, m32 = _model("bf16"), _model("fp32")
     m32.load_state_dict(m16.state_dict())
-    batch = lambda m, rows: data.gather(rows, xin_dtype=m._engine().enc[0].gt, apply_log=True, nb_const=True,  # noqa: E731
-                                        resident_rows=True)
+    batch = lambda m, rows: data.gather(rows, apply_log=True, nb_const=True, resident_rows=True,  # noqa: E731
+                                        **m._engine().input_spec())
     v1, g1 = _step(m16, batch(m16, idx), eps)
     v2, g2 = _step(m16, batch(m16, idx), eps)
     assert torch.equal(v1, v2) and all(torch.equal(g1[k], g2[k]) for k in g1), "the step is not deterministic"

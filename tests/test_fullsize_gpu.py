@@ -11,6 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 G, HIDDEN, L, C, B, N = 19000, [1024, 512], 64, 3, 4096, 6144
+# how a bf16-mode engine of this shape reads its encoder input (StepEngine.input_spec(); asserted in the fixture):
+# IEEE-half first-layer forward operand with a bf16 twin for the weight gradient, both centred on the dataset's gene means
+SPEC16 = dict(xin_dtype=torch.float16, centered=True, xin2=True)
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +36,8 @@ def world():
         models[prec] = Celligner2(G, HIDDEN, L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, beta=1.0,
                                   precision=prec).to(DEV).train()
     models["fp32"].load_state_dict(models["bf16"].state_dict())
+    assert models["bf16"]._engine().input_spec() == SPEC16
+    assert models["fp32"]._engine().input_spec() == dict(xin_dtype=torch.float32, centered=False, xin2=False)
     idx = torch.randperm(N, device=DEV, generator=g)[:B]
     eps = torch.randn(B, L, device=DEV, generator=g)
     return data, models, idx, eps
@@ -55,20 +60,20 @@ def _l2(a, b):
 def test_deterministic_and_resident_rows_equal_gathered_copies(world):
     data, models, idx, eps = world
     m = models["bf16"]
-    res = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=True)
+    res = data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **SPEC16)
     v1, g1 = _step(m, dict(res), eps)
     v2, g2 = _step(m, dict(res), eps)
     assert torch.equal(v1, v2)
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n  # split reductions are fixed-order slabs: bit-identical runs
-    cop = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=False)
+    cop = data.gather(idx, apply_log=True, nb_const=True, resident_rows=False, **SPEC16)
     assert "x" in cop and "x_full" in res and "x" not in res
     v3, g3 = _step(m, dict(cop), eps)
     assert torch.equal(v1, v3)
     for n in g1:
         assert torch.equal(g1[n], g3[n]), n
     # the encoder input left in the dataset's resident bf16 matrix, read in place by the row-indexed first-layer GEMMs
-    rx = data.gather(idx, xin_dtype=torch.bfloat16, apply_log=True, nb_const=True, resident_rows=True, resident_xin=True)
+    rx = data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, resident_xin=True, **SPEC16)
     assert "xin_full" in rx and "xin" not in rx and rx["row_index32"].dtype == torch.int32
     v4, g4 = _step(m, dict(rx), eps)
     assert torch.equal(v1, v4)
@@ -80,8 +85,8 @@ def test_row_permutation_invariance(world):
     data, models, idx, eps = world
     m = models["bf16"]
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
-    v1, g1 = _step(m, dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True)), eps)
-    v2, g2 = _step(m, dict(data.gather(idx[perm], torch.bfloat16, True, nb_const=True, resident_rows=True)), eps[perm])
+    v1, g1 = _step(m, dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **SPEC16)), eps)
+    v2, g2 = _step(m, dict(data.gather(idx[perm], apply_log=True, nb_const=True, resident_rows=True, **SPEC16)), eps[perm])
     assert torch.allclose(v1, v2, rtol=2e-5, atol=1e-6), (v1, v2)
     for n in g1:
         assert _l2(g2[n], g1[n]) < 2e-4, (n, _l2(g2[n], g1[n]))  # only the summation order over the batch differs
@@ -90,7 +95,7 @@ def test_row_permutation_invariance(world):
 def test_backward_is_linear_in_the_loss_weights(world):
     data, models, idx, eps = world
     m = models["bf16"]
-    batch = dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True))
+    batch = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **SPEC16))
     _, ga = _step(m, dict(batch), eps, (1.0, 0.0, 1.0, 1.0))
     _, gb = _step(m, dict(batch), eps, (1.0, 2.0, 1.0, 1.0))
     _, gm = _step(m, dict(batch), eps, (1.0, 1.0, 1.0, 1.0))
@@ -102,7 +107,7 @@ def test_backward_is_linear_in_the_loss_weights(world):
 def test_bf16_mode_agrees_with_fp32_mode(world):
     data, models, idx, eps = world
     batch32 = dict(data.gather(idx, torch.float32, True, nb_const=True, resident_rows=True))
-    batch16 = dict(data.gather(idx, torch.bfloat16, True, nb_const=True, resident_rows=True))
+    batch16 = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **SPEC16))
     v32, g32 = _step(models["fp32"], batch32, eps)
     v16, g16 = _step(models["bf16"], batch16, eps)
     assert torch.allclose(v16, v32, rtol=1e-2, atol=1e-4), (v16, v32)

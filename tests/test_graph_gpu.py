@@ -121,6 +121,13 @@ def test_dropout_masks_with_a_device_counter_continue_the_host_counters_stream()
         ops.dropout_masks_dev(b, 0.3, 99, ctr, adv)
         assert torch.equal(a, b), k
     assert int(ctr.item()) == 12345 + 3 * adv
+    # a rank's stretch of a data-parallel step's counter range: masks from counter + lead, counter += world x blocks
+    ctr = torch.tensor([500], dtype=torch.int64, device="cuda")
+    for k in range(2):
+        ops.dropout_masks(a, 0.3, 99, 500 + k * 4 * adv + 2 * adv)
+        ops.dropout_masks_dev(b, 0.3, 99, ctr, 4 * adv, lead=2 * adv)
+        assert torch.equal(a, b), k
+    assert int(ctr.item()) == 500 + 8 * adv
     assert abs(float(b.float().mean()) - (1 - 77 / 256)) < 0.02  # thresh8 = round(0.3*256) = 77
 
 

@@ -26,7 +26,7 @@ def rel(a, b):
     return gu.relerr(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2), (torch.float16, 1e-3)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 19000), (37, 300, 130), (4, 19000, 16), (512, 1000, 515)])
 def test_linear_three_layouts(dtype, tol, M, N, K):
     ops = _ops()
@@ -970,3 +970,111 @@ def test_decoder_output_softmax_and_relu(B, G):
     assert np.abs(sm.astype(np.float64).sum(1) - 1).max() < 1e-4
     assert np.array_equal(ops.decoder_output(t, "relu").cpu().numpy(), np.maximum(lg[:, :G], 0))
     assert ops.decoder_output(T(np.zeros((0, 5), np.float32)), "softmax").shape == (0, 5)
+
+
+@pytest.mark.parametrize("R,G", [(1, 5), (70, 76), (300, 1001), (4096, 19000)])
+def test_centred_encoder_input_entry_points(R, G):
+    """c2_col_mean / c2_prep_input + c2_gather_rows with a centre / c2_gemv_bias / c2_rank1_add: the four pieces of
+    h = (t(x) - c) W^T + (b + W c),  dW = dh^T (t(x) - c) + (sum dh) (x) c  (include/c2mi.h), each against numpy float64."""
+    ops = _ops()
+    rng = np.random.default_rng(R + G)
+    X = rng.poisson(rng.uniform(0.5, 2, (R, 1)) * np.exp(rng.normal(1.0, 1.0, (1, G)))).astype(np.float32)
+    t64 = np.log1p(X.astype(np.float64))
+    for log in (True, False):
+        want = (t64 if log else X.astype(np.float64)).mean(0)
+        c = ops.col_mean(T(X), log)
+        assert np.abs(c.cpu().numpy() - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0)
+    c = ops.col_mean(T(X), True)
+    c64 = c.double().cpu().numpy()
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2.0 ** -8)):
+        out = torch.empty(R, G, device=DEV, dtype=dt)
+        ops.prep_input(T(X), out, True, c)
+        d = t64 - c64
+        assert np.abs(out.double().cpu().numpy() - d).max() <= tol * max(np.abs(d).max(), 1e-3) + 1e-6
+    idx = rng.integers(0, R, 9).astype(np.int64)
+    xin = torch.empty(9, G, device=DEV, dtype=torch.bfloat16)
+    so = torch.empty(9, device=DEV)
+    ops.gather_rows(T(X), None, T(X.sum(1)), None, None, T(idx), None, None, so, None, None, xin, True, center=c)
+    ref = torch.empty(R, G, device=DEV, dtype=torch.bfloat16)
+    ops.prep_input(T(X), ref, True, c)
+    assert torch.equal(xin, ref[T(idx)])  # the gather and the whole-matrix conversion round the same values
+    # the centre's share of the layer and of its weight gradient
+    N = 37
+    W = rng.standard_normal((N, G)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    out = torch.empty(N, device=DEV)
+    ops.gemv_bias(T(W), c, T(b), out)
+    want = b + W.astype(np.float64) @ c64
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    ops.gemv_bias(T(W)[:, :G], c, None, out)
+    assert np.abs(out.cpu().numpy() - (want - b)).max() <= 1e-5 * np.abs(want).max()
+    g = rng.standard_normal((N, G)).astype(np.float32)
+    r = rng.standard_normal(N).astype(np.float32)
+    tg = T(g)
+    ops.rank1_add(tg, T(r), c)
+    assert np.abs(tg.cpu().numpy() - (g + np.outer(r, c64))).max() <= 1e-6 * np.abs(g).max() + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 19000), (4096, 1024, 2304), (128, 256, 19000), (37, 300, 130), (5, 64, 2048)])
+def test_linear_forward_on_ieee_half_operands(M, N, K):
+    """C2_F16 operands (the first layer's forward in bf16 mode): the LDS-DMA kernels' half-precision twin (256x256 and
+    128x128 tiles), its row-indexed form and the register-staged fallback, against numpy float64 on the rounded operands
+    (only the fp32 accumulation differs) -- and 8x closer to the unrounded product than bf16 operands."""
+    ops = _ops()
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ta, tw = T(a, torch.float16), T(w, torch.float16)
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(ta, tw, y, bias=T(bias))
+    ref = ta.double().cpu().numpy() @ tw.double().cpu().numpy().T + bias
+    assert rel(y, ref) < 1e-5
+    exact = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    yb = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(T(a, torch.bfloat16), T(w, torch.bfloat16), yb, bias=T(bias))
+    e16, eb = rel(y, exact), rel(yb, exact)
+    assert e16 < 0.25 * eb, (e16, eb)
+    if ops.gemm_tile(torch.float16, M, N, K) == 256 and M % 8 == 0:
+        n_res = M + 300
+        full = torch.randn(n_res, K, device=DEV).to(torch.float16)
+        rows = torch.randint(0, n_res, ((M + 63) // 64 * 64,), device=DEV).to(torch.int32)
+        y0, y1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        ops.linear_fwd(full[rows[:M].long()].contiguous(), tw, y0)
+        ops.linear_fwd_rows(full, rows, M, tw, y1)
+        assert torch.equal(y0, y1)
+
+
+def test_half_precision_outputs_of_the_input_kernels_and_adam():
+    """C2_F16 outputs: c2_prep_input, c2_gather_rows (xin as halves + its bf16 twin in the same pass), c2_cast_f16, and the
+    Adam kernel's half-precision operand copy (shadow_f16) -- each the correctly rounded value of the fp32 result."""
+    ops = _ops()
+    rng = np.random.default_rng(4)
+    for R, G in ((9, 76), (33, 1001)):
+        X = rng.poisson(4.0, (R, G)).astype(np.float32)
+        c = ops.col_mean(T(X), True)
+        t32 = torch.empty(R, G, device=DEV)
+        ops.prep_input(T(X), t32, True, c)
+        h = torch.empty(R, G, device=DEV, dtype=torch.float16)
+        ops.prep_input(T(X), h, True, c)
+        assert torch.equal(h, t32.to(torch.float16))
+        idx = T(rng.integers(0, R, 7).astype(np.int64))
+        xin = torch.empty(7, G, device=DEV, dtype=torch.float16)
+        g8 = (G + 7) // 8 * 8
+        xinb = torch.zeros(7, g8, device=DEV, dtype=torch.bfloat16)[:, :G]
+        so = torch.empty(7, device=DEV)
+        ops.gather_rows(T(X), None, T(X.sum(1)), None, None, idx, None, None, so, None, None, xin, True, center=c,
+                        xin2_out=xinb)
+        assert torch.equal(xin, t32[idx].to(torch.float16)) and torch.equal(xinb, t32[idx].to(torch.bfloat16))
+    p = torch.randn(1000, device=DEV) * 0.01
+    d = torch.empty(1000, device=DEV, dtype=torch.float16)
+    ops.cast_bf16(p, d)
+    assert torch.equal(d, p.to(torch.float16))
+    for n in (1024, 1003):
+        p = torch.randn(n, device=DEV) * 0.01
+        g, m, v = torch.randn(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sh = torch.empty(n, device=DEV, dtype=torch.float16)
+        p2, m2, v2 = p.clone(), m.clone(), v.clone()
+        ops.adam_step([(p, g, m, v, sh)], 1e-3, 0.9, 0.999, 0.01, 0.04, 0.0, 1)
+        ops.adam_step([(p2, g, m2, v2, None)], 1e-3, 0.9, 0.999, 0.01, 0.04, 0.0, 1)
+        assert torch.equal(p, p2) and torch.equal(sh, p.to(torch.float16))

@@ -38,3 +38,14 @@ def test_one_rank_over_rccl_issues_every_collective(variant):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tests", "ddp_worker.py"), variant]
     _run(cmd, env, "rccl1_" + variant)
+
+
+@pytest.mark.parametrize("variant", ["allreduce", "shard", "shard_bf16", "bn"])
+def test_data_parallel_step_replayed_as_a_graph(variant):
+    """Trainer(graph=True, world=...): the data-parallel iteration INCLUDING its RCCL collectives captured once and replayed
+    (one rank over RCCL issuing every collective, as above) == the same iteration launched kernel by kernel, bit for bit
+    (weights, optimizer step counts, logs).  Reference step being sharded: trainer.py:305-323."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", C2_DP_SINGLE_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(29860 + os.getpid() % 40), os.path.join(ROOT, "tests", "dp_graph_worker.py"), variant]
+    _run(cmd, env, "dpgraph_" + variant)

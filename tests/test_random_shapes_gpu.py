@@ -105,7 +105,7 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     xt = m._engine().enc[0].gt
     out = {}
     for resident in (True, False):
-        batch = dict(data.gather(idx, xin_dtype=xt, apply_log=True, nb_const=True, resident_rows=resident))
+        batch = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=resident, **m._engine().input_spec()))
         assert ("x_full" in batch) == resident
         if resident:
             assert batch["x_full"].stride(0) == (G + 3) // 4 * 4 and batch["goodloc_full"].stride(0) == (G + 3) // 4 * 4

@@ -110,7 +110,8 @@ elif rung in (4, 5, 6, 7, 8):
     eng0 = model._engine()
 
     def gather():
-        return ds.gather(idx, eng0.enc[0].gt, True, bufs, True, resident_rows=True, resident_xin=False)
+        return ds.gather(idx, apply_log=True, bufs=bufs, nb_const=True, resident_rows=True, resident_xin=False,
+                         **eng0.input_spec())
     batch = gather()
     w = torch.tensor([1.0, 0.1, 1.0, 1.0], device=dev)
     if rung == 4:
