@@ -128,7 +128,7 @@ class StepEngine:
         self._center = None
         # ... and, when that input is log(1 + x) (bounded by 89: in IEEE half's range whatever the counts), the first layer's
         # FORWARD reads input and weight as IEEE halves (C2_F16: 11 significant bits instead of bf16's 8, the same matrix
-        # rate).  Measured at 19 000 genes against the fp64 oracle (tests/test_benchwidth_oracle_gpu.py): the 2^-9 rounding
+        # rate).  Measured at 19 000 genes against the fp64 CPU restatement (tests/test_benchwidth_*_gpu.py): the 2^-9 rounding
         # of a bf16 encoder input put the latent heads' gradients at 1.8-3 %, beyond bf16 mode's 1e-2.  The layer's weight
         # gradient keeps bf16 operands (dh is a gradient: range matters more than digits), so the input exists in both forms.
         log_in = bool(cfg["applylog"]) and cfg["recon_loss"] != "mse"
