@@ -37,8 +37,9 @@ _SIGS = {
     "c2_last_error": (C.c_char_p, []),
     "c2_version": (i32, []),
     "c2_prep_input": (i32, [vp, i64, i64, i64, vp, i32, i64, i32, vp, vp]),
-    "c2_col_mean_ws": (sz, [i64, i64]),
-    "c2_col_mean": (i32, [vp, i64, i64, i64, i32, vp, vp, vp]),
+    "c2_col_sum_ws": (sz, [i64, i64]),
+    "c2_col_sum": (i32, [vp, i64, i64, i64, i32, vp, vp, vp]),
+    "c2_col_mean_from_sums": (i32, [vp, i64, i64, vp, vp]),
     "c2_gemv_bias": (i32, [vp, i64, i64, i64, vp, vp, vp, vp]),
     "c2_rank1_add": (i32, [vp, i64, i64, i64, vp, vp, vp]),
     "c2_drop_pending_sums": (i32, []),

@@ -925,31 +925,39 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
 // algebra, and the bf16 operand is now the small centred part; W c and the rank-one term are formed in fp32.
 // c = the per-gene mean of t(x) over the dataset (or over the batch, for batches handed in as tensors).
 //
-// column means of t(x) over the rows, two deterministic stages (no atomics)
-__global__ __launch_bounds__(256) void col_mean_stage1(const float* __restrict__ x, int64_t ldx, int64_t rows, int64_t cols,
-                                                       int apply_log, int nsplit, float* __restrict__ part) {
+// column sums of t(x) over the rows in DOUBLE, two deterministic stages (no atomics).  fp32 values summed in double are
+// exact for any batch this library sees, so the sum -- and the mean rounded to fp32 from it -- does not depend on how the
+// rows are cut into splits, or into ranks: N ranks that all-reduce their double sums centre on the same bits as one
+// process on the whole batch.
+__global__ __launch_bounds__(256) void col_sum_stage1(const float* __restrict__ x, int64_t ldx, int64_t rows, int64_t cols,
+                                                      int apply_log, int nsplit, double* __restrict__ part) {
     const int64_t c = blockIdx.x * 256ll + threadIdx.x;
     if (c >= cols) return;
     const int s = blockIdx.y;
     const int64_t per = (rows + nsplit - 1) / nsplit;
     const int64_t r0 = s * per, r1 = r0 + per < rows ? r0 + per : rows;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int64_t r = r0;
     for (; r + 3 < r1; r += 4) {
         float v0 = x[r * ldx + c], v1 = x[(r + 1) * ldx + c], v2 = x[(r + 2) * ldx + c], v3 = x[(r + 3) * ldx + c];
         if (apply_log) { v0 = log1p_count(v0); v1 = log1p_count(v1); v2 = log1p_count(v2); v3 = log1p_count(v3); }
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
     }
-    for (; r < r1; ++r) a0 += apply_log ? log1p_count(x[r * ldx + c]) : x[r * ldx + c];
+    for (; r < r1; ++r) a0 += (double)(apply_log ? log1p_count(x[r * ldx + c]) : x[r * ldx + c]);
     part[(int64_t)s * cols + c] = (a0 + a1) + (a2 + a3);
 }
-__global__ __launch_bounds__(256) void col_mean_stage2(const float* __restrict__ part, int nsplit, int64_t cols, float inv_rows,
-                                                       float* __restrict__ out) {
+__global__ __launch_bounds__(256) void col_sum_stage2(const double* __restrict__ part, int nsplit, int64_t cols,
+                                                      double* __restrict__ sums) {
     const int64_t c = blockIdx.x * 256ll + threadIdx.x;
     if (c >= cols) return;
-    float a = 0.f;
+    double a = 0.0;
     for (int s = 0; s < nsplit; ++s) a += part[(int64_t)s * cols + c];
-    out[c] = a * inv_rows;
+    sums[c] = a;
+}
+__global__ __launch_bounds__(256) void col_mean_finish(const double* __restrict__ sums, int64_t cols, double inv_rows,
+                                                       float* __restrict__ out) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c < cols) out[c] = (float)(sums[c] * inv_rows);
 }
 
 // out[n] = bias[n] + sum_k W[n][k] c[k]: one workgroup per output row, fp32, 16-byte loads where the row allows
@@ -1455,22 +1463,31 @@ extern "C" int c2_cast_f16(const float* src, void* dst, int64_t n, void* stream)
     return 0;
 }
 
-extern "C" size_t c2_col_mean_ws(int64_t rows, int64_t cols) {
-    const int64_t ns = std::max<int64_t>(1, std::min<int64_t>(64, rows / 64));
-    return (size_t)(ns * cols);
-}
+static int col_splits(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, rows / 64)); }
 
-extern "C" int c2_col_mean(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, float* out, float* ws,
-                           void* stream) {
+extern "C" size_t c2_col_sum_ws(int64_t rows, int64_t cols) { return (size_t)col_splits(rows) * (size_t)cols; }
+
+extern "C" int c2_col_sum(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, double* sums, double* ws,
+                          void* stream) {
     C2_CHECK(rows >= 0 && cols >= 0, "negative size");
     if (cols == 0) return 0;
-    C2_CHECK(out && ws, "null pointer");
-    C2_CHECK(rows > 0 && x && ldx >= cols, "bad arguments (the mean of no rows is undefined)");
-    const int ns = (int)std::max<int64_t>(1, std::min<int64_t>(64, rows / 64));
+    C2_CHECK(sums && ws, "null pointer");
+    C2_CHECK(rows == 0 || (x && ldx >= cols), "bad arguments");
+    const int ns = col_splits(rows);
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((cols + 255) / 256);
-    hipLaunchKernelGGL(col_mean_stage1, dim3(gx, ns), dim3(256), 0, st, x, ldx, rows, cols, apply_log, ns, ws);
-    hipLaunchKernelGGL(col_mean_stage2, dim3(gx), dim3(256), 0, st, (const float*)ws, ns, cols, 1.0f / (float)rows, out);
+    hipLaunchKernelGGL(col_sum_stage1, dim3(gx, ns), dim3(256), 0, st, x, ldx, rows, cols, apply_log, ns, ws);
+    hipLaunchKernelGGL(col_sum_stage2, dim3(gx), dim3(256), 0, st, (const double*)ws, ns, cols, sums);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_col_mean_from_sums(const double* sums, int64_t cols, int64_t total_rows, float* out, void* stream) {
+    C2_CHECK(cols >= 0 && total_rows > 0, "bad sizes (the mean of no rows is undefined)");
+    if (cols == 0) return 0;
+    C2_CHECK(sums && out, "null pointer");
+    hipLaunchKernelGGL(col_mean_finish, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, cols,
+                       1.0 / (double)total_rows, out);
     C2_LAUNCH_CHECK();
     return 0;
 }

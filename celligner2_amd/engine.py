@@ -619,19 +619,13 @@ class StepEngine:
         mean leaves the smallest operand).  [G rounded up to 8] fp32, pad zero."""
         B, G = x.shape
         c = self.buf("enc0.center", ((G + 7) // 8 * 8,), zero=True)
-        ops.col_mean(x, log_in, out=c, ws=self.buf("enc0.center.ws", (ops.col_mean_ws(B, G),)))
+        sums = ops.col_sum(x, log_in, self.buf("enc0.center.sums", (G,), torch.float64),
+                           self.buf("enc0.center.ws", (ops.col_sum_ws(B, G),), torch.float64))
         if self.exchange:
-            # ranks hold equal shares of the global batch: the mean of their means is the global batch's mean, so N ranks
-            # round the same operand values as one process on the whole batch
-            self.comm.allreduce_scalars(c)
-            ops.scale(c, self._inv_world(), c)
-        return c
-
-    def _inv_world(self):
-        c = self._ws.get("inv_world")
-        if c is None or c[0] != self.world_size:
-            c = self._ws["inv_world"] = (self.world_size, torch.full((1,), 1.0 / self.world_size, device=self.dev))
-        return c[1]
+            # ranks hold equal shares of the global batch; their double sums add up to the global batch's sum exactly, so
+            # N ranks round the same operand values as one process on the whole batch
+            self.comm.allreduce_scalars(sums)
+        return ops.col_mean_from_sums(sums, G, B * self.world_size, c)
 
     def _set_center(self, center):
         """Adopt the centre c of this batch's encoder input (or None): the first layer's bias becomes b + W c (fp32, from the

@@ -103,23 +103,40 @@ def prep_input(x, out, apply_log, center=None):
     return out
 
 
-def col_mean(x, apply_log, out=None, ws=None):
-    """[cols] fp32: mean over the rows of log(1 + x) (or x) -- the centre of the encoder input (c2mi.h, c2_col_mean)."""
+def col_sum(x, apply_log, sums=None, ws=None):
+    """[cols] float64: sum over the rows of log(1 + x) (or x), accumulated in double (order-independent: c2mi.h)."""
     L.require_gpu(x)
     rows, cols = x.shape
-    assert x.dtype == torch.float32 and rows > 0
-    if out is None:
-        out = torch.empty(cols, dtype=torch.float32, device=x.device)
-    need = int(lib.c2_col_mean_ws(rows, cols))
+    assert x.dtype == torch.float32
+    need = int(lib.c2_col_sum_ws(rows, cols))
+    if sums is None:
+        sums = torch.empty(cols, dtype=torch.float64, device=x.device)
     if ws is None:
-        ws = torch.empty(need, dtype=torch.float32, device=x.device)
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= cols and ws.numel() >= need
-    check(lib.c2_col_mean(ptr(x), _row_major(x, "x"), rows, cols, int(apply_log), ptr(out), ptr(ws), stream()))
+        ws = torch.empty(need, dtype=torch.float64, device=x.device)
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() >= cols
+    assert ws.dtype == torch.float64 and ws.numel() >= need
+    check(lib.c2_col_sum(ptr(x), _row_major(x, "x"), rows, cols, int(apply_log), ptr(sums), ptr(ws), stream()))
+    return sums
+
+
+def col_sum_ws(rows, cols):
+    return int(lib.c2_col_sum_ws(rows, cols))
+
+
+def col_mean_from_sums(sums, cols, total_rows, out):
+    L.require_gpu(sums, out)
+    assert sums.dtype == torch.float64 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= cols
+    check(lib.c2_col_mean_from_sums(ptr(sums), cols, int(total_rows), ptr(out), stream()))
     return out
 
 
-def col_mean_ws(rows, cols):
-    return int(lib.c2_col_mean_ws(rows, cols))
+def col_mean(x, apply_log, out=None):
+    """[cols] fp32: mean over the rows of log(1 + x) (or x) -- the centre of the encoder input (c2mi.h, c2_col_sum)."""
+    rows, cols = x.shape
+    assert rows > 0
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    return col_mean_from_sums(col_sum(x, apply_log), cols, rows, out)
 
 
 def gemv_bias(w, c, bias, out):

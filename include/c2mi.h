@@ -62,11 +62,15 @@ int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t ldx, void*
  *   dW = dh^T (t(x) - c) + (sum_b dh_b) (x) c       c2_linear_wgrad* + c2_rank1_add
  * which is the same layer, but the operand rounded to bf16 is the centred part: expression values share a large
  * per-gene level, and its 2^-9 rounding is what carried bf16 mode's gradient error past 1e-2 at 19 000 genes.
- *   c2_col_mean:  out[col] = mean over rows of t(x)[row][col]   (ws: c2_col_mean_ws(rows, cols) floats)
+ *   c2_col_sum:   sums[col] = sum over rows of t(x)[row][col] in double (ws: c2_col_sum_ws(rows, cols) doubles); summed
+ *                 in double the result does not depend on the order, so ranks that add their sums (an all-reduce) centre on
+ *                 the same bits as one process on the whole batch
+ *   c2_col_mean_from_sums: out[col] = (float)(sums[col] / total_rows)
  *   c2_gemv_bias: out[n] = bias[n] + sum_k W[n][k] c[k]          (fp32; bias may be NULL)
  *   c2_rank1_add: G[n][k] += r[n] * c[k] */
-size_t c2_col_mean_ws(int64_t rows, int64_t cols);
-int c2_col_mean(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, float* out, float* ws, void* stream);
+size_t c2_col_sum_ws(int64_t rows, int64_t cols);
+int c2_col_sum(const float* x, int64_t ldx, int64_t rows, int64_t cols, int apply_log, double* sums, double* ws, void* stream);
+int c2_col_mean_from_sums(const double* sums, int64_t cols, int64_t total_rows, float* out, void* stream);
 int c2_gemv_bias(const float* W, int64_t ldw, int64_t N, int64_t K, const float* c, const float* bias, float* out,
                  void* stream);
 int c2_rank1_add(float* G, int64_t ldg, int64_t N, int64_t K, const float* r, const float* c, void* stream);

@@ -1006,6 +1006,12 @@ def test_centred_encoder_input_entry_points(R, G):
     ops.gemv_bias(T(W), c, T(b), out)
     want = b + W.astype(np.float64) @ c64
     assert np.abs(out.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    # summed in double: the centre does not depend on how the rows are cut (ranks all-reduce their sums)
+    if R >= 2:
+        h = R // 2
+        both = ops.col_sum(T(X[:h]), True) + ops.col_sum(T(X[h:]), True)
+        c2 = ops.col_mean_from_sums(both, G, R, torch.empty(G, device=DEV))
+        assert torch.equal(c2, c)
     ops.gemv_bias(T(W)[:, :G], c, None, out)
     assert np.abs(out.cpu().numpy() - (want - b)).max() <= 1e-5 * np.abs(want).max()
     g = rng.standard_normal((N, G)).astype(np.float32)

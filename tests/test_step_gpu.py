@@ -107,7 +107,7 @@ def _run_case(z, meta, precision, tol):
                     stale = sh.clone()
                     sh = eng.weight(n)
                     assert not torch.equal(stale, sh), n
-                assert torch.equal(sh, dict(model.named_parameters())[n].detach().to(torch.bfloat16)), n
+                assert torch.equal(sh, dict(model.named_parameters())[n].detach().to(sh.dtype)), n
 
 
 def test_state_dict_and_init_match_reference_layout():
@@ -334,7 +334,7 @@ def test_bf16_operand_copies_follow_the_optimizer():
         params = dict(m.named_parameters())
         assert len(eng._wplanes) >= 4 and len(eng._shadow) == 2
         for n, sh in eng._shadow.items():
-            assert torch.equal(sh, params[n].detach().to(torch.bfloat16)), (n, step)
+            assert torch.equal(sh, params[n].detach().to(sh.dtype)), (n, step)
         for n, (_, pl) in eng._wplanes.items():
             if n == eng.HEADW:  # the two latent heads' weights stacked [2L, H]
                 w = torch.cat([params[h + ".weight"].detach() for h in eng.HEADS], 0)
