@@ -35,11 +35,25 @@ _DEFAULTS = {"use_own_kl_": False, "use_bn_": False, "use_ln_": True, "apply_log
              "batch_knowledge_": True, "classifier_hidden_layer_sizes_": [], "mmd_boundary_": None}
 
 
-def public_attributes(model: Celligner2, condition_keys=None, predictor_keys=None, miss=(), is_trained=False, **extra):
-    """The wrapper's `<name>_` attribute dict (celligner2_model.py:218-272) for a bare module."""
+def public_attributes(model: Celligner2, condition_keys=None, predictor_keys=None, miss="U", is_trained=False,
+                      condition_set=None, predictor_set=None, **extra):
+    """The wrapper's `<name>_` attribute dict (celligner2_model.py:171-272) for a bare module: the key set and value types
+    of what the reference's `save` pickles (pinned by tests/golden/checkpoint_dir.npz, written by the reference itself).
+    condition_set / predictor_set: obs column -> set of its labels (celligner2_model.py:180-223); by default a single key
+    owns every label of the module, several keys get empty sets (the split is the AnnData's knowledge, not the module's).
+    miss: the wrapper's marker(s) for a missing label, kept as given (the reference's default is the string "U")."""
+    def label_sets(keys, given, labels):
+        if given is not None:
+            return {k: set(v) for k, v in given.items()}
+        if not keys:
+            return {}
+        return {k: (set(labels) if len(keys) == 1 else set()) for k in keys}
+
     d = {
         "condition_keys_": condition_keys, "conditions_": list(model.conditions), "predictor_keys_": predictor_keys,
-        "predictors_": list(model.predictors), "miss_": list(miss),
+        "predictors_": list(model.predictors), "miss_": miss,
+        "condition_set_": label_sets(condition_keys, condition_set, model.conditions),
+        "predictor_set_": label_sets(predictor_keys, predictor_set, model.predictors),
         "hidden_layer_sizes_": list(model.hidden_layer_sizes),
         "classifier_hidden_layer_sizes_": list(model.classifier_hidden_layer_sizes), "latent_dim_": model.latent_dim,
         "dr_rate_": model.dr_rate, "use_mmd_": model.use_mmd, "mmd_on_": model.mmd_on,

@@ -89,3 +89,52 @@ def test_new_conditions_from_obs():
         surgery.new_conditions_from_obs({"a": ["v"], "b": ["v"]}, ["a", "b"], [])
     with pytest.raises(ValueError, match="missing"):
         surgery.new_conditions_from_obs({"a": ["v", "nan"]}, ["a"], [], miss=["nan"])
+
+
+def test_checkpoint_directory_written_by_the_reference(tmp_path):
+    """tests/golden/checkpoint_dir.npz holds the three files the reference's own BaseMixin.save wrote
+    (othermodels/base/_base.py:47-95; tools/gen_golden_checkpoint.py, `pdb.set_trace` a no-op as in SURVEY.md App. C).
+    The directory rebuilt from those bytes must load here with loaders that execute nothing from the files, rebuild the
+    module with the same state, and `surgery.save` must write the same layout: the same attr.pkl key set and value types,
+    var_names.csv byte for byte, the same state_dict keys / shapes / dtypes."""
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_dir.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    d = tmp_path / "ref_ck"
+    os.makedirs(d)
+    assert meta["files"] == ["attr.pkl", "model_params.pt", "var_names.csv"]
+    for f in meta["files"]:
+        with open(d / f, "wb") as fh:
+            fh.write(bytes(z["file/" + f]))
+    attrs, state, names = surgery.load_params(str(d))
+    # what the fixture says the reference pickled (recorded as JSON when it was made): same keys, same types
+    assert set(attrs) == set(meta["attrs"])
+    for k, (tname, val) in meta["attrs"].items():
+        assert type(attrs[k]).__name__ == tname, k
+        if tname in ("bool", "int", "float", "str", "NoneType", "list"):
+            assert attrs[k] == val, k
+    assert attrs["condition_set_"] == {"dataset": {"ccle", "tcga"}} and attrs["miss_"] == "U"
+    assert list(names) == meta["var_names"]
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in state.items()] == meta["state"]
+    # the module rebuilt from the reference's attributes takes the reference's state_dict as it is
+    m, attrs2, _ = surgery.load(str(d), device="cpu")
+    assert list(m.state_dict()) == [k for k, _, _ in meta["state"]]
+    for k, v in state.items():
+        assert torch.equal(m.state_dict()[k], v), k
+    assert (m.input_dim, m.hidden_layer_sizes, m.latent_dim, m.conditions, m.predictors) == \
+        (40, [20, 10], 5, ["ccle", "tcga"], ["lung", "skin", "blood"])
+    assert m.recon_loss == "nb" and m.use_mmd and m.beta == 7.0 and m.classifier_hidden_layer_sizes == [12]
+    # ... and what surgery.save writes for it has the reference's layout
+    mine = surgery.public_attributes(m, condition_keys=attrs["condition_keys_"], predictor_keys=attrs["predictor_keys_"],
+                                     miss=attrs["miss_"], predictor_set=attrs["predictor_set_"])
+    assert set(mine) == set(attrs)
+    for k in attrs:
+        assert type(mine[k]) is type(attrs[k]), k
+        assert mine[k] == attrs[k], k
+    d2 = tmp_path / "my_ck"
+    surgery.save(str(d2), m, mine, names)
+    assert sorted(os.listdir(d2)) == meta["files"]
+    assert open(d2 / "var_names.csv", "rb").read() == bytes(z["file/var_names.csv"])
+    attrs3, state3, _ = surgery.load_params(str(d2))
+    assert attrs3 == attrs
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in state3.items()] == meta["state"]
