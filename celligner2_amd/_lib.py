@@ -69,7 +69,9 @@ _SIGS = {
     "c2_reparam_kl_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, vp, vp, i64, i64, i64, f32, i32, vp, vp, vp, i32, i64, vp]),
     "c2_recon_nb_ws": (sz, [i64, i64, i32]),
     "c2_recon_nb_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp]),
-    "c2_recon_nb_fwd_bwd_dbias": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "c2_recon_nb_logits_f16_ok": (i32, [i64, i64]),
+    "c2_linear_fwd_f16out": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, vp, vp]),
+    "c2_recon_nb_fwd_bwd_dbias": (i32, [vp, i32, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]),
     "c2_recon_zinb_fwd_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, vp, i32, i64,
                                     i64, vp, vp, vp, vp, vp]),
     "c2_recon_zinb_fwd_bwd_rc": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, i64, i64, f32, vp, vp, vp, i32,

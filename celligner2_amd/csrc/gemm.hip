@@ -293,7 +293,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < a.M && col < a.N) C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + bv;
+                if (row < a.M && col < a.N) {
+                    if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)row * a.ldc + col] = (f16_t)(alpha * acc[i][j][e] + bv);
+                    else C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + bv;
+                }
             }
         }
 }
@@ -450,6 +453,23 @@ extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t 
         a.B_lo = (const bf16_t*)W + N * ldw;
     }
     C2_CHECK(gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_fwd_f16out(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
+                                    int64_t K, void* Y16, int64_t ldy, const float* bias, void* stream) {
+    C2_CHECK(gemm_args_ok(dtype, M, N, K, 1), "bad dtype/shape");
+    C2_CHECK(A && W && Y16, "null pointer");
+    C2_CHECK(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs a{A, W, reinterpret_cast<float*>(Y16), bias, nullptr, lda, ldw, ldy, 0, (int)M, (int)N, (int)K, 0, nullptr, nullptr,
+               nullptr, 1};
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = (const bf16_t*)A + M * lda;
+        a.B_lo = (const bf16_t*)W + N * ldw;
+    }
+    C2_CHECK(gemm_dispatch(0, dtype, a, 1, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }

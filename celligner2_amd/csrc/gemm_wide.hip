@@ -588,17 +588,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
             f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
             const int row = m0 + wm * (MI * 32) + half * 64 + r;
             if (row < a.M) {
-                float* dst = C + (int64_t)row * a.ldc + col4;
-                if (vec_ok) {
-                    f32x4 o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = alpha * v[c] + bv[c];
-                    *reinterpret_cast<f32x4*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (col4 + c < a.N) dst[c] = alpha * v[c] + bv[c];
-                }
+                store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites
@@ -903,17 +893,7 @@ __global__ __launch_bounds__(1024) void gemm_wide16_kernel(GemmArgs a, int tiles
             f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
             const int row = m0 + wm * 64 + qt * 32 + r;
             if (row < a.M) {
-                float* dst = C + (int64_t)row * a.ldc + col4;
-                if (vec_ok) {
-                    f32x4 o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = alpha * v[c] + bv[c];
-                    *reinterpret_cast<f32x4*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (col4 + c < a.N) dst[c] = alpha * v[c] + bv[c];
-                }
+                store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next quarter overwrites
@@ -1074,17 +1054,7 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
         f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * WCOLS + (lane % LPR) * 4);
         const int row = m0 + wm * (MI * 32) + r;
         if (row < a.M) {
-            float* dst = C + (int64_t)row * a.ldc + col4;
-            if (vec_ok) {
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = alpha * v[c] + bv[c];
-                *reinterpret_cast<f32x4*>(dst) = o;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (col4 + c < a.N) dst[c] = alpha * v[c] + bv[c];
-            }
+            store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
         }
     }
 }

@@ -7,6 +7,8 @@
 // goodloc 1G read, dlogits (2|4)G written: the algorithmic minimum.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace c2 {
@@ -485,7 +487,9 @@ __device__ __forceinline__ float nb_block_reduce(float v, float* red, int& half)
 // REGT (512 threads x 10 chunks at 19k genes: two waves per SIMD, 256 registers each): theta of the thread's genes and
 // the dispersion-gradient accumulator live in REGISTERS as well -- the row loop then reads no table at all and the only
 // LDS traffic left is p * dloss/dp between the passes (one LDS row: G <= 40 000 fits, NV caps it at 20 480 here).
-template <typename TD, int NT, int NV, bool HAS_LGX, bool REGT = false>
+// LH: the logits are IEEE halves (c2_linear_fwd_f16out): 8 bytes per lane and chunk instead of 16, widened when the row's
+// turn comes.
+template <typename TD, int NT, int NV, bool HAS_LGX, bool REGT = false, bool LH = false>
 __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     static_assert(NV >= 2, "the rolling prefetch of counts reaches two chunks ahead");
     extern __shared__ __attribute__((aligned(16))) float dacc[];
@@ -569,7 +573,9 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
 #pragma unroll
         for (int i = 0; i < (REGT ? NV : 1); ++i) asm volatile("" : "+v"(thr[i]));
     };
-    f32x4 ev[NV], nx[NV];
+    typedef typename std::conditional<LH, u32x2, f32x4>::type nx_t;
+    f32x4 ev[NV];
+    nx_t nx[NV];
     f32x4 xq[3];       // counts of chunks i, i+1, i+2 (slot = chunk % 3)
     unsigned mq[3];    // their masks
     f32x4 tq[2];       // theta of this chunk's four genes and of the next chunk's (slot = chunk % 2)
@@ -583,8 +589,22 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
     };
     const int v16 = tid * 16;
-    auto load_o = [&](int i, __amdgpu_buffer_rsrc_t r) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v16, i * NT * 16, 0));
+    auto load_o = [&](int i, __amdgpu_buffer_rsrc_t r) -> nx_t {
+        if constexpr (LH) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, i * NT * 8, 0));
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v16, i * NT * 16, 0));
+    };
+    auto logits_rsrc = [&](int64_t r) {  // the logits of batch row r as a buffer of its G elements
+        if constexpr (LH) return row_rsrc(reinterpret_cast<const f16_t*>(a.logits) + r * a.ldl, Gi * 2);
+        else return row_rsrc(a.logits + r * a.ldl, Gi * 4);
+    };
+    auto widen = [&](const nx_t& v) -> f32x4 {
+        if constexpr (LH) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const h2 lo = __builtin_bit_cast(h2, v[0]), hi = __builtin_bit_cast(h2, v[1]);
+            return f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
+        } else {
+            return v;
+        }
     };
     auto load_x = [&](int i, __amdgpu_buffer_rsrc_t rx) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, v16, i * NT * 16, 0));
@@ -606,7 +626,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         const int64_t srow = a.ridx ? a.ridx[row] : row;
         const auto rx = row_rsrc(a.x + srow * a.ldx, Gi * 4);
         const auto rg = row_rsrc(a.goodloc + srow * a.ldg, Gi);
-        const auto rl = row_rsrc(a.logits + row * a.ldl, Gi * 4);
+        const auto rl = logits_rsrc(row);
 #pragma unroll
         for (int i = 0; i < NV; ++i) nx[i] = load_o(i, rl);
 #pragma unroll
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         }
         ++rows_kept;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) ev[i] = nx[i];
+        for (int i = 0; i < NV; ++i) ev[i] = widen(nx[i]);
         const bool rotate = true;
         const int64_t srow_c = meta.srow;
         const auto rxc = row_rsrc(a.x + srow_c * a.ldx, Gi * 4);
@@ -686,7 +706,7 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         // the same order, which is what lets the compiler count its vmcnt waits exactly -- with a shorter last-row path
         // merged in, the waits of the final chunks of EVERY row were full drains)
         const int64_t nsrow = has_next ? nmeta.srow : srow_c;
-        const auto nrl = row_rsrc(a.logits + (has_next ? nrow : row) * a.ldl, Gi * 4);
+        const auto nrl = logits_rsrc(has_next ? nrow : row);
         const auto nrx = row_rsrc(a.x + nsrow * a.ldx, Gi * 4);
         const auto nrg = row_rsrc(a.goodloc + nsrow * a.ldg, Gi);
         const float sf = meta.sf;
@@ -1465,6 +1485,31 @@ static NbFast zinb_fast_shape(int64_t G, bool vec) {
     return {0, 0};
 }
 
+// the fast kernel on half-precision logits: the two shapes of 18 432 < G <= 20 480 genes (768 x 7, 512 x 10), bf16 dlogits
+static bool nb_logits_f16_shape(int64_t G, bool vec, int64_t B) {
+    const NbFast f = nb_fast_shape(G, vec, B);
+    return (f.nt == 768 && f.nv == 7) || (f.nt == 512 && f.nv == 10);
+}
+static int nb_launch_lh(NbArgs a, int ngroups, hipStream_t st) {
+    const size_t l = 2 * (size_t)((a.G + 3) & ~int64_t(3)) * sizeof(float);
+    const NbFast f = nb_fast_shape(a.G, true, a.B);
+#define NB_H(NT, NV)                                                                                          \
+    do {                                                                                                      \
+        constexpr bool regt = (NT) == 512;                                                                     \
+        auto kf = nb_rowreg_kernel<bf16_t, NT, NV, false, regt, true>;                                         \
+        auto kl = nb_rowreg_kernel<bf16_t, NT, NV, true, regt, true>;                                          \
+        (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);              \
+        (void)hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);              \
+        if (a.lgx) hipLaunchKernelGGL(kl, dim3(ngroups), dim3(NT), l, st, a);                                  \
+        else hipLaunchKernelGGL(kf, dim3(ngroups), dim3(NT), l, st, a);                                        \
+        return 0;                                                                                             \
+    } while (0)
+    if (f.nt == 768 && f.nv == 7) NB_H(768, 7);
+    if (f.nt == 512 && f.nv == 10) NB_H(512, 10);
+#undef NB_H
+    return 1;
+}
+
 template <typename TD>
 static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     const size_t lds = (size_t)((a.G + 3) & ~int64_t(3)) * sizeof(float);
@@ -1512,15 +1557,17 @@ static int nb_launch(NbArgs a, int ngroups, bool vec, hipStream_t st) {
     return 0;
 }
 
-static int recon_nb_run(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+static int recon_nb_run(const void* logits_any, int l_dtype, int64_t ldl, const float* x, int64_t ldx,
                                    const uint8_t* goodloc, int64_t ldg, const float* sizefactor, const float* theta,
                                    const int64_t* cond, int C, int64_t B, int64_t G, float inv_B, float* loss_out,
                                    void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
                                    int32_t* status_dev, const float* lgx1_rowsum, const int64_t* row_index,
                                    float* dbias, void* stream) {
+    const float* logits = reinterpret_cast<const float*>(logits_any);
     C2_CHECK(logits && x && goodloc && sizefactor && theta && cond && loss_out && dlogits && dtheta && ws && status_dev,
              "null pointer");
     C2_CHECK(dl_dtype == C2_F32 || dl_dtype == C2_BF16, "bad dtype");
+    C2_CHECK(l_dtype == C2_F32 || l_dtype == C2_F16, "logits are fp32 or IEEE halves");
     C2_CHECK(C >= 1, "NB needs at least one condition column (theta is [G,C])");
     C2_CHECK(ldl >= G && ldx >= G && ldg >= G && lddl >= G, "leading dimension too small");
     C2_CHECK(G <= 40000, "G > 40000 genes is not supported by the NB kernel (its LDS accumulator holds G floats)");
@@ -1545,7 +1592,15 @@ static int recon_nb_run(const float* logits, int64_t ldl, const float* x, int64_
     // the loss kernel forms the column sums itself in its register-resident form; otherwise a column-sum pass follows
     const bool db_in_kernel = dbias && nb_fast_shape(G, vec, B).nt == 512;
     if (db_in_kernel) a.part_db = part_db;
-    int rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
+    int rc;
+    if (l_dtype == C2_F16) {
+        C2_CHECK(dl_dtype == C2_BF16 && nb_logits_f16_shape(G, vec, B),
+                 "half-precision logits: bf16 dlogits, 16-byte aligned rows and 18 432 < G <= 20 480 only "
+                 "(c2_recon_nb_logits_f16_ok); hand fp32 logits otherwise");
+        rc = nb_launch_lh(a, ngroups, st);
+    } else {
+        rc = dl_dtype == C2_BF16 ? nb_launch<bf16_t>(a, ngroups, vec, st) : nb_launch<float>(a, ngroups, vec, st);
+    }
     C2_CHECK(rc == 0, "unsupported G");
     if (ngroups <= kDthDirect && B <= kDthDirect && !db_in_kernel) {
         const dim3 grid((unsigned)((G + 63) / 64));
@@ -1580,18 +1635,20 @@ extern "C" int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float
                                    void* dlogits, int dl_dtype, int64_t lddl, float* dtheta, float* ws,
                                    int32_t* status_dev, const float* lgx1_rowsum, const int64_t* row_index,
                                    void* stream) {
-    return recon_nb_run(logits, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
+    return recon_nb_run(logits, C2_F32, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
                         dl_dtype, lddl, dtheta, ws, status_dev, lgx1_rowsum, row_index, nullptr, stream);
 }
 
-extern "C" int c2_recon_nb_fwd_bwd_dbias(const float* logits, int64_t ldl, const float* x, int64_t ldx,
+extern "C" int c2_recon_nb_logits_f16_ok(int64_t B, int64_t G) { return nb_logits_f16_shape(G, G % 4 == 0, B) ? 1 : 0; }
+
+extern "C" int c2_recon_nb_fwd_bwd_dbias(const void* logits, int l_dtype, int64_t ldl, const float* x, int64_t ldx,
                                          const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
                                          const float* theta, const int64_t* cond, int C, int64_t B, int64_t G,
                                          float inv_B, float* loss_out, void* dlogits, int dl_dtype, int64_t lddl,
                                          float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,
                                          const int64_t* row_index, float* dbias, void* stream) {
     C2_CHECK(dbias, "null pointer");
-    return recon_nb_run(logits, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
+    return recon_nb_run(logits, l_dtype, ldl, x, ldx, goodloc, ldg, sizefactor, theta, cond, C, B, G, inv_B, loss_out, dlogits,
                         dl_dtype, lddl, dtheta, ws, status_dev, lgx1_rowsum, row_index, dbias, stream);
 }
 

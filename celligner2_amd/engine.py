@@ -887,13 +887,26 @@ class StepEngine:
         G4 = (G + 3) // 4 * 4
         wide4 = (G4 != G and cfg["recon_loss"] in ("nb", "zinb") and x is None and batch["x_full"].stride(0) == G4
                  and batch["goodloc_full"].stride(0) == G4)
+        # bf16 mode, NB likelihood at the widths its register-resident kernel takes: the logits leave the output layer's GEMM
+        # as IEEE halves (2^-12 of a logit; the same mode rounds the layer's operands and dlogits to 2^-9) -- half the
+        # bytes of the step's largest store, and of the loss kernel's largest read
+        want_db = save and cfg["recon_loss"] == "nb" and self.p[self.head + ".bias"].requires_grad
+        half_logits = (self.head_t == torch.bfloat16 and cfg["recon_loss"] == "nb" and not wide4 and want_db
+                       and d.dtype == torch.bfloat16 and ops.nb_logits_f16_ok(B, G))
         if wide4:
             logits4 = self.buf("logits4", (B, G4))
             logits4[:, G:].fill_(-float("inf"))
             logits = self._ws["logits"] = logits4[:, :G]
+        elif half_logits:
+            logits = self.buf("logits16", (B, G), torch.float16)
+            self._ws["logits"] = logits
         else:
             logits = self.buf("logits", (B, G))
-        self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
+        if half_logits:
+            a_, w_ = self._widened(d, self.weight(self.head + ".weight"))
+            ops.linear_fwd_f16out(a_, w_, logits, bias=self.p[self.head + ".bias"].detach())
+        else:
+            self._fwd(d, self.head + ".weight", logits, bias=self.p[self.head + ".bias"].detach())
         # ---- reconstruction loss (+ its unit-upstream gradient)
         dlogits = self.abuf("dlogits", (B, G), self.head_t)
         if wide4 and dlogits.stride(0) < G4:  # (fp32 mode: abuf pads 2-byte rows only)
@@ -905,7 +918,6 @@ class StepEngine:
             else:
                 xs, gl, ridx = x, batch["goodloc"], None
             # the loss kernel also sums dlogits over the batch (the output layer's bias gradient) while it has them
-            want_db = save and self.p[self.head + ".bias"].requires_grad
             theta = self.p["theta"].detach()
             if wide4:
                 widen = lambda t: t.as_strided((t.shape[0], G4), (t.stride(0), 1), t.storage_offset())  # noqa: E731

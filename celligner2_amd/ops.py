@@ -176,6 +176,22 @@ def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
     return y
 
 
+def linear_fwd_f16out(a, w, y, bias=None, x3=False):
+    """y = a @ w.T (+bias) rounded to IEEE halves (y: [M, N] float16): the decoder's logits in bf16 mode."""
+    L.require_gpu(a, w, y)
+    (M, K), lda, code = _operand(a, "a", x3)
+    (N, K2), ldw, code_w = _operand(w, "w", x3)
+    assert K2 == K and code == code_w and y.dtype == torch.float16 and tuple(y.shape) == (M, N)
+    with _GemmTimer(M, N, K):
+        check(lib.c2_linear_fwd_f16out(ptr(a), lda, ptr(w), ldw, code, M, N, K, ptr(y), _row_major(y, "y"), ptr(bias),
+                                       stream()))
+    return y
+
+
+def nb_logits_f16_ok(B, G):
+    return bool(lib.c2_recon_nb_logits_f16_ok(B, G))
+
+
 def _rows_arg(a_full, rows, need, dtypes=(torch.bfloat16,)):
     assert a_full.dtype in dtypes and a_full.dim() == 2 and a_full.stride(1) == 1
     assert rows.dtype == torch.int32 and rows.is_contiguous() and rows.numel() >= need
@@ -489,6 +505,8 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
     assert x.shape[1] == G and goodloc.shape == x.shape and (row_index is not None or x.shape[0] == B)
     if row_index is not None:
         assert row_index.dtype == torch.int64 and row_index.is_contiguous() and row_index.numel() == B and row_index.is_cuda
+    assert logits.dtype == torch.float32 or (logits.dtype == torch.float16 and dbias is not None), \
+        "half-precision logits go through the entry point that also forms the bias gradient"
     C = theta.shape[1]
     assert goodloc.dtype in (torch.bool, torch.uint8) and theta.is_contiguous() and cond.is_contiguous()
     assert cond.dtype == torch.int64 and tuple(cond.shape) == (B, C) and dtheta.is_contiguous()
@@ -497,7 +515,8 @@ def recon_nb(logits, x, goodloc, sizefactor, theta, cond, inv_B, loss_out, dlogi
         assert lgx1.dtype == torch.float32 and lgx1.is_contiguous() and lgx1.numel() == B and lgx1.is_cuda
     if dbias is not None:
         assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == G and dbias.is_cuda
-        check(lib.c2_recon_nb_fwd_bwd_dbias(ptr(logits), _row_major(logits, "logits"), ptr(x), _row_major(x, "x"),
+        check(lib.c2_recon_nb_fwd_bwd_dbias(ptr(logits), dt_code(logits.dtype), _row_major(logits, "logits"), ptr(x),
+                                            _row_major(x, "x"),
                                             ptr(goodloc), _row_major(goodloc, "goodloc"), ptr(sizefactor), ptr(theta),
                                             ptr(cond), C, B, G, float(inv_B), ptr(loss_out), ptr(dlogits),
                                             dt_code(dlogits.dtype), _row_major(dlogits, "dlogits"), ptr(dtheta), ptr(ws),

@@ -82,6 +82,12 @@ int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dt
                   int64_t K, float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                   void* stream);
 
+/* c2_linear_fwd with the output rounded to IEEE halves (Y16: [M][ldy] halves, unsplit, bias optional): the decoder's
+ * logits in bf16 mode (modules.py:478-482 feeds them to Softmax; celligner2/model/losses.py:27-65 reads the result).  A
+ * half keeps 2^-12 of a logit, below the 2^-9 at which the same mode rounds dlogits. */
+int c2_linear_fwd_f16out(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
+                         int64_t K, void* Y16, int64_t ldy, const float* bias, void* stream);
+
 /* autograd of the same Linear w.r.t. its input:
  *   dA[s][m][k] = alpha * sum_{n in split s} dY[m][n] * W[n][k]      alpha = *alpha_dev or 1 */
 int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
@@ -209,7 +215,11 @@ int c2_recon_nb_fwd_bwd(const float* logits, int64_t ldl, const float* x, int64_
  * gradient of the Linear that produced the logits (modules.py:471-477, decoder.recon_decoder; autograd's column sum
  * of the output gradient), taken from the values before they are rounded to dl_dtype.  The register-resident form of
  * the loss kernel accumulates it beside the row walk; other shapes run a column-sum pass over dlogits. */
-int c2_recon_nb_fwd_bwd_dbias(const float* logits, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
+/* l_dtype: C2_F32, or C2_F16 -- logits as IEEE halves [B][ldl] (c2_linear_fwd_f16out), taken by the register-resident
+ * forms of the kernel only: bf16 dlogits, 16-byte aligned rows and 18 432 < G <= 20 480 genes (the benchmark widths);
+ * c2_recon_nb_logits_f16_ok(B, G) says whether a shape qualifies, any other use of C2_F16 is an error. */
+int c2_recon_nb_logits_f16_ok(int64_t B, int64_t G);
+int c2_recon_nb_fwd_bwd_dbias(const void* logits, int l_dtype, int64_t ldl, const float* x, int64_t ldx, const uint8_t* goodloc,
                               int64_t ldg, const float* sizefactor, const float* theta, const int64_t* cond, int C,
                               int64_t B, int64_t G, float inv_B, float* loss_out, void* dlogits, int dl_dtype,
                               int64_t lddl, float* dtheta, float* ws, int32_t* status_dev, const float* lgx1_rowsum,

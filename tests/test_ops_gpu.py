@@ -1084,3 +1084,55 @@ def test_half_precision_outputs_of_the_input_kernels_and_adam():
         ops.adam_step([(p, g, m, v, sh)], 1e-3, 0.9, 0.999, 0.01, 0.04, 0.0, 1)
         ops.adam_step([(p2, g, m2, v2, None)], 1e-3, 0.9, 0.999, 0.01, 0.04, 0.0, 1)
         assert torch.equal(p, p2) and torch.equal(sh, p.to(torch.float16))
+
+
+@pytest.mark.parametrize("M,N,K,dtype", [(256, 19000, 1024, torch.bfloat16), (128, 19000, 256, torch.bfloat16),
+                                         (37, 300, 130, torch.bfloat16), (64, 200, 96, torch.float32)])
+def test_linear_forward_with_half_precision_output(M, N, K, dtype):
+    """c2_linear_fwd_f16out: the forward GEMM's result rounded once to IEEE halves == the fp32 result of c2_linear_fwd
+    rounded by torch (every kernel family: 256x256 and 128x128 LDS-DMA tiles, the register-staged kernel, bf16x3)."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).to(dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+    y32 = torch.empty(M, N, device=DEV)
+    y16 = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    x3 = dtype == torch.float32
+    ops.linear_fwd(a, w, y32, bias=bias, x3=x3)
+    ops.linear_fwd_f16out(a, w, y16, bias=bias, x3=x3)
+    assert torch.equal(y16, y32.to(torch.float16))
+
+
+@pytest.mark.parametrize("B,G", [(300, 19000), (64, 19000), (40, 20480), (33, 18436)])
+def test_recon_nb_on_half_precision_logits(B, G):
+    """The NB loss kernel fed IEEE-half logits (both register-resident forms: B above and below the workgroup count) ==
+    the same kernel fed those halves widened to fp32, bit for bit: loss, dlogits, dtheta, the bias gradient."""
+    ops = _ops()
+    assert ops.nb_logits_f16_ok(B, G) and not ops.nb_logits_f16_ok(B, 4096) and not ops.nb_logits_f16_ok(B, 19001)
+    rng = np.random.default_rng(B + G)
+    C = 3
+    x = T(rng.poisson(rng.uniform(0.5, 2, (B, 1)) * np.exp(rng.normal(1.0, 1.5, (1, G)))).astype(np.float32))
+    good = T(rng.uniform(size=(B, G)) > 0.01)
+    lg16 = T((rng.standard_normal((B, G)) * 2).astype(np.float32)).to(torch.float16)
+    cond = np.zeros((B, C), np.int64)
+    cond[np.arange(B), rng.integers(0, C, B)] = 1
+    theta = T((rng.standard_normal((G, C)) * 0.5).astype(np.float32))
+    sf = x.sum(1)
+    out = []
+    for lg in (lg16, lg16.float()):
+        loss = torch.zeros(1, device=DEV)
+        dl = torch.empty(B, G, device=DEV, dtype=torch.bfloat16)
+        dth = torch.empty(G, C, device=DEV)
+        db = torch.empty(G, device=DEV)
+        ws = torch.empty(ops.recon_nb_ws(B, G, C), device=DEV)
+        st = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.recon_nb(lg, x, good, sf, theta, T(cond), 1.0 / B, loss, dl, dth, ws, st, dbias=db)
+        assert int(st.item()) == 0
+        out.append((loss.clone(), dl, dth, db))
+    for u, v in zip(*out):
+        assert torch.equal(u, v)
+    with pytest.raises(ops.L.C2Error):  # a width outside the register-resident forms: fp32 logits only
+        ops.recon_nb(lg16[:, :4096].contiguous(), x[:, :4096].contiguous(), good[:, :4096].contiguous(), sf,
+                     theta[:4096].contiguous(), T(cond), 1.0 / B, loss, torch.empty(B, 4096, device=DEV, dtype=torch.bfloat16),
+                     torch.empty(4096, C, device=DEV), ws, st, dbias=torch.empty(4096, device=DEV))

@@ -40,7 +40,49 @@ def run(name, variant):
                            masks={k: torch.tensor(v.astype(np.uint8)).cuda() for k, v in masks.items()})
     eng = m._engine()
     hw = eng.head + ".weight"
-    if variant != "base" and variant != "enc0_x3":
+    if variant.startswith("narrow16"):
+        # what single-product IEEE-half narrow GEMMs would do to the gradients: the bf16x3 path on operands rounded to
+        # halves first (fwd: forward GEMMs only; all: forward, input-gradient and weight-gradient GEMMs)
+        h16 = lambda t: t.to(torch.float16).float()  # noqa: E731
+        o_fwd, o_ls, o_dg, o_wg = eng._fwd, eng._linear_slabs, eng._dgrad, eng._wgrad
+        f32 = torch.float32
+
+        def w16(name, fn):
+            if name is None or eng.gemm_dtype(name) != f32 or name == eng.HEADW:
+                return fn()
+            p_ = eng.p[name]
+            keep = p_.data.clone()
+            p_.data.copy_(h16(keep))
+            eng._wplanes.pop(name, None)
+            try:
+                return fn()
+            finally:
+                p_.data.copy_(keep)
+                eng._wplanes.pop(name, None)
+
+        def ls(key, a, wname, B, _o=o_ls):
+            if isinstance(a, tuple) or a.dtype != f32:
+                return _o(key, a, wname, B)
+            eng._aplanes.pop((a.data_ptr(), tuple(a.shape)), None)
+            a2 = h16(a)
+            return w16(wname, lambda: _o(key, a2, wname, B))
+        eng._linear_slabs = ls
+        if variant == "narrow16_all":
+            def dg(dy, wname, out_slabs, alpha=None, _o=o_dg):
+                if dy.dtype != f32:
+                    return _o(dy, wname, out_slabs, alpha)
+                s_ = 4096.0
+                d2 = h16(dy * s_) / s_
+                return w16(wname, lambda: _o(d2, wname, out_slabs, alpha))
+            eng._dgrad = dg
+
+            def wg(dy, a, name, alpha=None, g=None, _o=o_wg):
+                if isinstance(a, tuple) or dy.dtype != f32 or a.dtype != f32:
+                    return _o(dy, a, name, alpha, g)
+                s_ = 4096.0
+                return _o(h16(dy * s_) / s_, h16(a), name, alpha, g)
+            eng._wgrad = wg
+    elif variant != "base" and variant != "enc0_x3":
         eng.head_t = F32
         eng.dec[-1].out_t = F32
         gd = eng.gemm_dtype
@@ -80,5 +122,6 @@ def run(name, variant):
 
 if __name__ == "__main__":
     case = sys.argv[1] if len(sys.argv) > 1 else "c4"
-    for v in ("base", "head_x3", "enc0_x3", "both_x3", "+dl_rounded", "+w_rounded", "+fwd_rounded"):
+    variants = sys.argv[2:] or ["base", "head_x3", "enc0_x3", "both_x3", "+dl_rounded", "+w_rounded", "+fwd_rounded"]
+    for v in variants:
         run(case, v)
