@@ -599,9 +599,13 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
     };
     auto widen = [&](const nx_t& v) -> f32x4 {
         if constexpr (LH) {
-            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-            const h2 lo = __builtin_bit_cast(h2, v[0]), hi = __builtin_bit_cast(h2, v[1]);
-            return f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
+            // (bit tests, not a cast of the dwords to half pairs: hipcc 7.2 returned the FIRST dword's halves for both
+            // `__builtin_bit_cast(half2, v[0])` and `(..., v[1])` -- tools/dbg/half_load_test.hip)
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = (float)__builtin_bit_cast(f16_t, (unsigned short)((v[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+            return w;
         } else {
             return v;
         }
