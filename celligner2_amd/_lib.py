@@ -29,6 +29,10 @@ class AdamState(C.Structure):
                 ("clip_value", f64)]
 
 
+class SlabSum(C.Structure):
+    _fields_ = [("slabs", vp), ("out", vp), ("slab_stride", i64), ("n", i64), ("nslab", i32)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp), ("shadow_f16", i32)]
 
@@ -45,15 +49,16 @@ _SIGS = {
     "c2_drop_pending_sums": (i32, []),
     "c2_linear_fwd": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
     "c2_linear_dgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
-    "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad": (i32, [vp, i64, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "c2_linear_fwd_rows": (i32, [vp, i64, i64, vp, vp, i64, i32, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
-    "c2_linear_wgrad_rows": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
-    "c2_linear_wgrad_rows_at": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
-    "c2_linear_wgrad_bt": (i32, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad_rows": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
+    "c2_linear_wgrad_rows_at": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
+    "c2_linear_wgrad_bt": (i32, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "c2_gemm_tile": (i32, [i32, i64, i64, i64]),
     "c2_split_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs_2d": (i32, [vp, i32, i64, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
+    "c2_sum_slabs_multi": (i32, [C.POINTER(SlabSum), i32, vp]),
     "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp, vp]),
     "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp, vp]),
     "c2_bn_ws": (sz, [i64, i64]),

@@ -27,12 +27,21 @@ struct GemmArgs {
     // logits in bf16 mode -- the 311 MB fp32 store of the 4096 x 19 000 forward becomes 155 MB, and the loss kernel reads
     // 155 MB less.
     int c_f16;
+    // Rank-one term of the epilogue: C[row][col] += rowscale[row] * bias[col] (the first split of a split reduction adds
+    // it, once).  The first layer's weight gradient with a centred input: dW = dh^T (x - c) + (sum_b dh_b) (x) c.
+    const float* rowscale;
 };
 
 // One 4-column piece of an output row: alpha * v + bias, as fp32 or halves.  dst_row: the row's first element (fp32 view of
 // C); col: first of the four columns; vec: the 4 columns exist and the address is aligned for one store.
 __device__ __forceinline__ void store_out4(const GemmArgs& a, float* C, int64_t row, int col, const f32x4& v, float alpha,
-                                           const float (&bv)[4], bool vec) {
+                                           const float (&bv0)[4], bool vec, bool first_split = true) {
+    float bv[4] = {bv0[0], bv0[1], bv0[2], bv0[3]};
+    if (a.rowscale) {
+        const float rs = first_split ? a.rowscale[row] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c] *= rs;
+    }
     if (a.c_f16) {
         f16_t* dst = reinterpret_cast<f16_t*>(C) + row * a.ldc + col;
         if (vec) {

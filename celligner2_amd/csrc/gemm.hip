@@ -294,8 +294,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (row < a.M && col < a.N) {
-                    if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)row * a.ldc + col] = (f16_t)(alpha * acc[i][j][e] + bv);
-                    else C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + bv;
+                    const float add = a.rowscale ? (split == 0 ? bv * a.rowscale[row] : 0.f) : bv;
+                    if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)row * a.ldc + col] = (f16_t)(alpha * acc[i][j][e] + add);
+                    else C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + add;
                 }
             }
         }
@@ -356,6 +357,35 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, int
         float s = 0.f;
         for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
         out[i] = s;
+    }
+}
+
+// several split reductions closed by ONE launch (the narrow layers' weight gradients at the end of a backward pass): a table
+// of jobs by value, each block owns 1024 consecutive elements of one job
+constexpr int kMaxSlabJobs = 16;
+struct SlabJobs {
+    c2_slab_sum job[kMaxSlabJobs];
+    int first_block[kMaxSlabJobs + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SlabJobs t) {
+    int j = 0;
+    while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const c2_slab_sum d = t.job[j];
+    const int64_t i0 = ((int64_t)blockIdx.x - t.first_block[j]) * 1024 + threadIdx.x * 4;
+    if (i0 >= d.n) return;
+    const bool vec = ((d.slab_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.slabs) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && i0 + 4 <= d.n;
+    if (vec) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < d.nslab; ++k) s += *reinterpret_cast<const f32x4*>(d.slabs + k * d.slab_stride + i0);
+        *reinterpret_cast<f32x4*>(d.out + i0) = s;
+    } else {
+        for (int64_t i = i0; i < i0 + 4 && i < d.n; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < d.nslab; ++k) s += d.slabs[k * d.slab_stride + i];
+            d.out[i] = s;
+        }
     }
 }
 
@@ -496,7 +526,7 @@ extern "C" int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_row
 
 extern "C" int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64_t lda, int64_t a_rows,
                                     const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw,
-                                    int nslab, int64_t slab_stride, const float* alpha_dev, void* stream) {
+                                    int nslab, int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream) {
     C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
     C2_CHECK(dY && A_full && row_index && dW, "null pointer");
     C2_CHECK(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
@@ -506,6 +536,8 @@ extern "C" int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_
     // C[n][k] = sum_m dY[m][n] A[rows[m]][k]: A-op = dY (XC over n), B-op = A_full (XC over k, reduction rows indexed)
     GemmArgs a{dY, A_full, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr,
                row_index};
+    C2_CHECK(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
+    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
     int64_t per = (a.R + nslab - 1) / nslab;
     a.r_per_split = (int)((per + 63) / 64 * 64);
     C2_CHECK(launch_gemm_wide_rows(2, a, nslab, (hipStream_t)stream) == 0,
@@ -516,7 +548,7 @@ extern "C" int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_
 
 extern "C" int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const void* A_full, int64_t lda, int64_t a_rows,
                                        const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw,
-                                       int nslab, int64_t slab_stride, const float* alpha_dev, void* stream) {
+                                       int nslab, int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream) {
     C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
     C2_CHECK(dYt && A_full && row_index && dW, "null pointer");
     C2_CHECK(lddyt >= M && lda >= K && lddw >= K, "leading dimension too small");
@@ -526,6 +558,8 @@ extern "C" int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const voi
     // C[n][k] = sum_m dYt[n][m] A[rows[m]][k]: A-op = dYt (RC over m), B-op = A_full (XC over k, reduction rows indexed)
     GemmArgs a{dYt, A_full, dW, nullptr, alpha_dev, lddyt, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr,
                row_index};
+    C2_CHECK(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
+    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
     int64_t per = (a.R + nslab - 1) / nslab;
     a.r_per_split = (int)((per + 63) / 64 * 64);
     C2_CHECK(launch_gemm_wide_rows(4, a, nslab, (hipStream_t)stream) == 0,
@@ -536,7 +570,7 @@ extern "C" int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const voi
 
 extern "C" int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, int64_t ldat, int64_t M, int64_t N,
                                   int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
-                                  const float* alpha_dev, void* stream) {
+                                  const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream) {
     C2_CHECK(gemm_args_ok(C2_BF16, M, N, K, nslab), "bad shape");
     C2_CHECK(dY && At && dW, "null pointer");
     C2_CHECK(lddy >= N && ldat >= M && lddw >= K, "leading dimension too small");
@@ -544,6 +578,8 @@ extern "C" int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, 
     if (N == 0 || K == 0) return 0;
     // C[n][k] = sum_m dY[m][n] At[k][m]: A-op = dY (XC over n), B-op = At (RC over m)
     GemmArgs a{dY, At, dW, nullptr, alpha_dev, lddy, ldat, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
+    C2_CHECK(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
+    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
     C2_CHECK(gemm_dispatch(3, C2_BF16, a, nslab, (hipStream_t)stream) == 0,
              "shape/alignment not taken by the 256x256 LDS-DMA kernel (see c2_gemm_tile): use c2_linear_wgrad");
     C2_LAUNCH_CHECK();
@@ -571,7 +607,7 @@ extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int6
 
 extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, int dtype, int64_t M,
                                int64_t N, int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
-                               const float* alpha_dev, void* stream) {
+                               const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream) {
     C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
     C2_CHECK(dY && A && dW, "null pointer");
     C2_CHECK(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
@@ -579,6 +615,8 @@ extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int6
     if (N == 0 || K == 0) return 0;
     // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
     GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
+    C2_CHECK(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
+    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
     if (dtype == C2_BF16X3P) {
         a.A_lo = (const bf16_t*)dY + M * lddy;
         a.B_lo = (const bf16_t*)A + M * lda;
@@ -595,6 +633,29 @@ extern "C" int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_strid
     int blocks = (int)std::min<int64_t>((rows * cols + 255) / 256, 2048);
     hipLaunchKernelGGL(sum_slabs_2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslab, slab_stride, rows,
                        cols, lds, out, ldo);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_sum_slabs_multi(const c2_slab_sum* jobs_host, int n_jobs, void* stream) {
+    C2_CHECK(n_jobs >= 0 && (n_jobs == 0 || jobs_host), "bad arguments");
+    for (int i = 0; i < n_jobs;) {
+        SlabJobs t;
+        t.n = 0;
+        int blocks = 0;
+        for (; i < n_jobs && t.n < kMaxSlabJobs; ++i) {
+            const c2_slab_sum& d = jobs_host[i];
+            if (d.n == 0) continue;
+            C2_CHECK(d.slabs && d.out && d.nslab >= 1 && d.n > 0 && d.slab_stride >= d.n, "bad job");
+            t.job[t.n] = d;
+            t.first_block[t.n] = blocks;
+            blocks += (int)((d.n + 1023) / 1024);
+            ++t.n;
+        }
+        t.first_block[t.n] = blocks;
+        if (t.n == 0) break;
+        hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t);
+    }
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
             f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
             const int row = m0 + wm * (MI * 32) + half * 64 + r;
             if (row < a.M) {
-                store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
+                store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(1024) void gemm_wide16_kernel(GemmArgs a, int tiles
             f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
             const int row = m0 + wm * 64 + qt * 32 + r;
             if (row < a.M) {
-                store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
+                store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next quarter overwrites
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
         f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * WCOLS + (lane % LPR) * 4);
         const int row = m0 + wm * (MI * 32) + r;
         if (row < a.M) {
-            store_out4(a, C, row, col4, v, alpha, bv, vec_ok);
+            store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
         }
     }
 }

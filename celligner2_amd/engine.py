@@ -75,6 +75,7 @@ class StepEngine:
         self._wplanes = {}   # bf16x3: (version, [2,N,K] bf16 planes) of the fp32 weights of the narrow layers
         self._aplanes = {}   # bf16x3: planes of this step's fp32 activations / gradients, by (data_ptr, shape)
         self.grad = {}
+        self._slab_jobs = None  # list while a backward pass runs: (slabs, gradient view) of split weight gradients to be summed
         self._touched = set()
         self.world_size, self.rank = 1, 0
         self.comm = None  # set by parallel.DataParallelStep
@@ -283,6 +284,7 @@ class StepEngine:
         return self.grad[name]
 
     def _reduce_bucket(self, i):
+        self._flush_slab_sums()  # a bucket is complete only once the split weight gradients that wait are summed
         if self.exchange:
             lo, hi = self.buckets[i]
             if hi > lo:
@@ -509,44 +511,57 @@ class StepEngine:
         ops.linear_fwd(a2, w2, y, nslab=ns, x3=self.x3)
         return y
 
-    def _wgrad(self, dy, a, name, alpha=None, g=None):
-        """grad[name] = alpha * dy^T a; a short-and-wide weight gradient splits the batch reduction into slabs so
-        that the launch fills the chip, then sums them (deterministic)."""
+    def _wgrad(self, dy, a, name, alpha=None, g=None, rank1=None):
+        """grad[name] = alpha * dy^T a (+ r (x) c for rank1 = (r [N], c [K]), added in the GEMM's epilogue); a
+        short-and-wide weight gradient splits the batch reduction into slabs so that the launch fills the chip, then
+        sums them (deterministic)."""
         if g is None:
             g = self.gbuf(name)
         N, K = g.shape
         if isinstance(a, tuple):  # (resident bf16 matrix, int32 row index): gene-width by construction
             dy = self._narrow_t(dy, "dyt", N, K, a[0])  # (the narrow operand transposed: see _narrow_t)
-            if not self._wgrad_two_part(dy, a, g, alpha):
+            if not self._wgrad_two_part(dy, a, g, alpha, rank1):
                 ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
                 if ns == 1:
-                    self._wg(dy, a, g, alpha=alpha)
+                    self._wg(dy, a, g, alpha=alpha, rank1=rank1)
                 else:
                     slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
-                    self._wg(dy, a, slabs, nslab=ns, alpha=alpha)
+                    self._wg(dy, a, slabs, nslab=ns, alpha=alpha, rank1=rank1)
                     ops.sum_slabs(slabs, g)
             return
         dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
         if not pl:
             at = self._narrow_t(a, "at", N, K, dy)
-            if self._wgrad_two_part(dy, at, g, alpha):
+            if self._wgrad_two_part(dy, at, g, alpha, rank1):
                 return
             if isinstance(at, _T):
                 ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3)
                 if ns == 1:
-                    self._wg(dy, at, g, alpha=alpha)
+                    self._wg(dy, at, g, alpha=alpha, rank1=rank1)
                 else:
                     slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
-                    self._wg(dy, at, slabs, nslab=ns, alpha=alpha)
+                    self._wg(dy, at, slabs, nslab=ns, alpha=alpha, rank1=rank1)
                     ops.sum_slabs(slabs, g)
                 return
         ns = ops.pick_nslab(N, K, dy.shape[0], dy.dtype, self.x3, planes=pl)
         if ns == 1:
-            ops.linear_wgrad(dy2, a2, g, alpha=alpha, x3=self.x3)
+            ops.linear_wgrad(dy2, a2, g, alpha=alpha, x3=self.x3, rank1=rank1)
+        elif self._slab_jobs is not None and g.is_contiguous():
+            # a narrow layer inside a backward pass: its slabs wait (in a buffer of their own) for the one launch that
+            # closes all of them (_flush_slab_sums)
+            slabs = self.buf(f"wgrad.slabs.{name or 'heads'}.{ns}x{N}x{K}", (ns, N, K))
+            ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3, rank1=rank1)
+            self._slab_jobs.append((slabs, g))
         else:
             slabs = self.buf(f"wgrad.slabs.{ns}x{N}x{K}", (ns, N, K))
-            ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3)
+            ops.linear_wgrad(dy2, a2, slabs, nslab=ns, alpha=alpha, x3=self.x3, rank1=rank1)
             ops.sum_slabs(slabs, g)
+
+    def _flush_slab_sums(self):
+        """Close the split reductions that wait in self._slab_jobs with one launch (c2_sum_slabs_multi)."""
+        if self._slab_jobs:  # (None outside a backward pass)
+            ops.sum_slabs_multi(self._slab_jobs)
+            self._slab_jobs.clear()
 
     def _narrow_t(self, t, key, N, K, other):
         """A gene-width bf16 weight gradient [N, K] reduced over the batch multiplies faster when its NARROW operand
@@ -564,22 +579,22 @@ class StepEngine:
         return _T(ops.transpose_bf16(t, self.buf(f"wgrad.{key}.{H}x{B}", (H, B), torch.bfloat16)))
 
     @staticmethod
-    def _wg(dy, a, out, nslab=1, alpha=None, cols=None):
+    def _wg(dy, a, out, nslab=1, alpha=None, cols=None, rank1=None):
         """Weight-gradient launch for a plain activation matrix or a (resident matrix, row index) pair; cols: column
         slice of the activation.  A _T operand is the transposed copy _narrow_t made (dy for the row-indexed form, the
         activation otherwise); slices of it are taken along its rows."""
         if isinstance(a, tuple):
             af = a[0] if cols is None else a[0][:, cols]
             if isinstance(dy, _T):
-                ops.linear_wgrad_rows_at(dy.t, af, a[1], out, nslab=nslab, alpha=alpha)
+                ops.linear_wgrad_rows_at(dy.t, af, a[1], out, nslab=nslab, alpha=alpha, rank1=rank1)
             else:
-                ops.linear_wgrad_rows(dy, af, a[1], out, nslab=nslab, alpha=alpha)
+                ops.linear_wgrad_rows(dy, af, a[1], out, nslab=nslab, alpha=alpha, rank1=rank1)
         elif isinstance(a, _T):
-            ops.linear_wgrad_bt(dy, a.t if cols is None else a.t[cols], out, nslab=nslab, alpha=alpha)
+            ops.linear_wgrad_bt(dy, a.t if cols is None else a.t[cols], out, nslab=nslab, alpha=alpha, rank1=rank1)
         else:
-            ops.linear_wgrad(dy, a if cols is None else a[:, cols], out, nslab=nslab, alpha=alpha)
+            ops.linear_wgrad(dy, a if cols is None else a[:, cols], out, nslab=nslab, alpha=alpha, rank1=rank1)
 
-    def _wgrad_two_part(self, dy, a, g, alpha):
+    def _wgrad_two_part(self, dy, a, g, alpha, rank1=None):
         """A gene-width weight gradient whose 256x256 tiles number a little more than a multiple of the 256 CUs
         (19000 x 1024: 300 tiles = two rounds, the second 17 % full) runs as two launches: the tiles of the full
         rounds unsplit, the remaining strip with its batch reduction split into slabs so that it is one short round."""
@@ -602,15 +617,16 @@ class StepEngine:
             return False
         tiles2 = ((rest + 255) // 256) * per
         ns = max(1, min(16, 256 // tiles2, M // 256))
+        r1 = (lambda rs, cs: None) if rank1 is None else (lambda rs, cs: (rank1[0][rs], rank1[1][cs]))  # noqa: E731
         if by_rows:
-            self._wg(_cols(dy, slice(0, cut)), a, g[:cut], alpha=alpha)
+            self._wg(_cols(dy, slice(0, cut)), a, g[:cut], alpha=alpha, rank1=r1(slice(0, cut), slice(0, K)))
             slabs = self.buf(f"wgrad.strip.{ns}x{rest}x{K}", (ns, rest, K))
-            self._wg(_cols(dy, slice(cut, None)), a, slabs, nslab=ns, alpha=alpha)
+            self._wg(_cols(dy, slice(cut, None)), a, slabs, nslab=ns, alpha=alpha, rank1=r1(slice(cut, N), slice(0, K)))
             ops.sum_slabs(slabs, g[cut:])
         else:
-            self._wg(dy, a, g[:, :cut], alpha=alpha, cols=slice(0, cut))
+            self._wg(dy, a, g[:, :cut], alpha=alpha, cols=slice(0, cut), rank1=r1(slice(0, N), slice(0, cut)))
             slabs = self.buf(f"wgrad.strip.{ns}x{N}x{rest}", (ns, N, rest))
-            self._wg(dy, a, slabs, nslab=ns, alpha=alpha, cols=slice(cut, None))
+            self._wg(dy, a, slabs, nslab=ns, alpha=alpha, cols=slice(cut, None), rank1=r1(slice(0, N), slice(cut, K)))
             ops.sum_slabs_2d(slabs, g[:, cut:])
         return True
 
@@ -715,18 +731,19 @@ class StepEngine:
                              self._ws[blk.name + ".yhat"], self._ws[blk.name + ".rstd"], dh, extra=extra,
                              extra_scale=extra_scale, planes=planes)
         need_w = self.p[blk.w].requires_grad
-        if need_w:
-            self._wgrad(dh, a_in, blk.w)
         need_b = blk.b is not None and self.p[blk.b].requires_grad
         need_c = blk.wc is not None and self.p[blk.wc].requires_grad
-        centred = blk is self.enc[0] and self._center is not None and need_w  # dW += (sum_b dh_b) (x) c
+        # a centred first layer: dW = dh^T (x - c) + (sum_b dh_b) (x) c -- the column sums of dh (the bias gradient) come
+        # first, the rank-one term rides in the weight-gradient GEMM's epilogue
+        centred = blk is self.enc[0] and self._center is not None and need_w
+        db = None
         if need_b or need_c or centred:
             C = cond.shape[1] if need_c else 0
             ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
             db = self.gbuf(blk.b) if need_b else (self.buf("enc0.dhsum", (H,)) if centred else None)
             ops.bias_cond_grad(dh, cond if need_c else None, db, self.gbuf(blk.wc) if need_c else None, ws)
-            if centred:
-                ops.rank1_add(self.grad[blk.w], db, self._center)
+        if need_w:
+            self._wgrad(dh, a_in, blk.w, rank1=(db, self._center) if centred else None)
         if not need_da:
             return None
         K = self.p[blk.w].shape[1]
@@ -1024,6 +1041,13 @@ class StepEngine:
         cfg = self.cfg
         B, cond, masks = self._B, self._cond, self._masks
         self._touched = set()  # parameters outside this step's graph get no gradient (torch leaves .grad None)
+        self._slab_jobs = []
+        try:
+            return self._backward(g, cfg, B, cond, masks)
+        finally:
+            self._slab_jobs = None
+
+    def _backward(self, g, cfg, B, cond, masks):
         gr, gk, gm, gc = g[0:1], g[1:2], g[2:3], g[3:4]
         rq = lambda n: self.p[n].requires_grad  # noqa: E731
         dlogits = self._ws["dlogits"]
@@ -1128,6 +1152,7 @@ class StepEngine:
             if i == 0:
                 self._reduce_bucket(1)  # overlaps the gene-width wgrad of encoder L0
             da = self._block_bwd(self.enc[i], da, self._enc_in[i], cond, masks, need_da=(i > need))
+        self._flush_slab_sums()
         if need > 0:
             self._reduce_bucket(1)
         self._reduce_bucket(2)

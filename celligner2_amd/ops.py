@@ -212,7 +212,18 @@ def linear_fwd_rows(a_full, rows, M, w, y, bias=None, nslab=1):
     return y
 
 
-def linear_wgrad_rows(dy, a_full, rows, dw, nslab=1, alpha=None):
+def _rank1(rank1, N, K):
+    """(row vector [N], column vector [K]) of the epilogue's rank-one term, as pointers (None, None when absent)."""
+    if rank1 is None:
+        return None, None
+    r, c = rank1
+    L.require_gpu(r, c)
+    assert r.dtype == torch.float32 and c.dtype == torch.float32 and r.is_contiguous() and c.is_contiguous()
+    assert r.numel() == N and c.numel() >= K
+    return ptr(r), ptr(c)
+
+
+def linear_wgrad_rows(dy, a_full, rows, dw, nslab=1, alpha=None, rank1=None):
     """dw[s] = alpha * dy.T @ a_full[rows[:M]]; rows must be readable up to M rounded up to 64."""
     L.require_gpu(dy, a_full, rows, dw)
     M, N = dy.shape
@@ -225,11 +236,11 @@ def linear_wgrad_rows(dy, a_full, rows, dw, nslab=1, alpha=None):
     with _GemmTimer(M, N, K):
         check(lib.c2_linear_wgrad_rows(ptr(dy), _row_major(dy, "dy"), ptr(a_full), a_full.stride(0), a_full.shape[0],
                                        ptr(rows), M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss, ptr(alpha),
-                                       stream()))
+                                       *_rank1(rank1, N, K), stream()))
     return dw
 
 
-def linear_wgrad_rows_at(dyt, a_full, rows, dw, nslab=1, alpha=None):
+def linear_wgrad_rows_at(dyt, a_full, rows, dw, nslab=1, alpha=None, rank1=None):
     """linear_wgrad_rows with dy handed over transposed: dyt [N, M] bf16 (the cells contiguous)."""
     L.require_gpu(dyt, a_full, rows, dw)
     N, M = dyt.shape
@@ -242,11 +253,11 @@ def linear_wgrad_rows_at(dyt, a_full, rows, dw, nslab=1, alpha=None):
     with _GemmTimer(M, N, K):
         check(lib.c2_linear_wgrad_rows_at(ptr(dyt), _row_major(dyt, "dyt"), ptr(a_full), a_full.stride(0),
                                           a_full.shape[0], ptr(rows), M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
-                                          ptr(alpha), stream()))
+                                          ptr(alpha), *_rank1(rank1, N, K), stream()))
     return dw
 
 
-def linear_wgrad_bt(dy, at, dw, nslab=1, alpha=None):
+def linear_wgrad_bt(dy, at, dw, nslab=1, alpha=None, rank1=None):
     """dw[s] = alpha * dy.T @ at.T with the second operand handed over transposed: dy [M, N], at [K, M], both bf16."""
     L.require_gpu(dy, at, dw)
     M, N = dy.shape
@@ -257,7 +268,7 @@ def linear_wgrad_bt(dy, at, dw, nslab=1, alpha=None):
     ss = dw.stride(0) if dw.dim() == 3 else 0
     with _GemmTimer(M, N, K):
         check(lib.c2_linear_wgrad_bt(ptr(dy), _row_major(dy, "dy"), ptr(at), _row_major(at, "at"), M, N, K, ptr(dw),
-                                     _row_major(d2, "dw"), nslab, ss, ptr(alpha), stream()))
+                                     _row_major(d2, "dw"), nslab, ss, ptr(alpha), *_rank1(rank1, N, K), stream()))
     return dw
 
 
@@ -277,7 +288,7 @@ def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     return da
 
 
-def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False):
+def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False, rank1=None):
     """dw[s] = alpha * dy.T @ a.   dy [M,N], a [M,K], dw [N,K] or [nslab,N,K]."""
     L.require_gpu(dy, a, dw)
     (M, N), lddy, code = _operand(dy, "dy", x3)
@@ -289,7 +300,7 @@ def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False):
     assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
         check(lib.c2_linear_wgrad(ptr(dy), lddy, ptr(a), lda, code, M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
-                                  ptr(alpha), stream()))
+                                  ptr(alpha), *_rank1(rank1, N, K), stream()))
     return dw
 
 
@@ -298,6 +309,21 @@ def sum_slabs(slabs, out):
     assert slabs.is_contiguous() and out.is_contiguous() and slabs.numel() == slabs.shape[0] * n
     check(lib.c2_sum_slabs(ptr(slabs), slabs.shape[0], n, ptr(out), n, stream()))
     return out
+
+
+def sum_slabs_multi(jobs):
+    """jobs: [(slabs [S, ...], out [...])]: every out = its slabs summed over S, one launch for all."""
+    n = len(jobs)
+    if n == 0:
+        return
+    arr = (L.SlabSum * n)()
+    for i, (slabs, out) in enumerate(jobs):
+        L.require_gpu(slabs, out)
+        m = out.numel()
+        assert slabs.is_contiguous() and out.is_contiguous() and slabs.numel() == slabs.shape[0] * m
+        assert slabs.dtype == torch.float32 and out.dtype == torch.float32
+        arr[i] = L.SlabSum(ptr(slabs), ptr(out), m, m, slabs.shape[0])
+    check(lib.c2_sum_slabs_multi(arr, n, stream()))
 
 
 def sum_slabs_2d(slabs, out):

@@ -38,6 +38,18 @@ class FusedAdam(torch.optim.Optimizer):
     def _sharded(self):
         return self._grad_sync is not None and getattr(self._grad_sync, "sharded", False)
 
+    def state_dict(self):
+        """Refused in the sharded form: every rank holds full-shape moment tensors but maintains only the elements of its
+        own chunks (parallel.DataParallelStep(shard_optimizer=True)), so what any single rank would save is mostly stale
+        -- resuming from it, or changing the world size, would silently diverge.  Checkpoint the MODEL (its state_dict is
+        complete on every rank after each step), or run the all-reduce form (shard_optimizer=False), whose optimizer
+        state is whole on every rank."""
+        if self._sharded():
+            raise RuntimeError("FusedAdam.state_dict(): the optimizer state is sharded over the ranks (shard_optimizer=True): "
+                               "each rank maintains the moments of its own chunks only; save the model's state_dict, or "
+                               "use shard_optimizer=False for a checkpointable optimizer")
+        return super().state_dict()
+
     @staticmethod
     def _hyper_of(group):
         return (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],

@@ -95,10 +95,12 @@ int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, in
                     const float* alpha_dev, void* stream);
 
 /* autograd of the same Linear w.r.t. its weight:
- *   dW[s][n][k] = alpha * sum_{m in split s} dY[m][n] * A[m][k] */
+ *   dW[s][n][k] = alpha * sum_{m in split s} dY[m][n] * A[m][k]   (+ rank1_row[n] * rank1_col[k] in split 0)
+ * rank1_row [N] / rank1_col [K] (both or neither; also on the _rows, _rows_at and _bt forms): a rank-one term added in the
+ * epilogue -- the centred first layer's (sum_b dh_b) (x) c (see c2_col_sum), without a pass of its own over dW. */
 int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, int dtype, int64_t M, int64_t N,
                     int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
-                    const float* alpha_dev, void* stream);
+                    const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream);
 
 /* Row-indexed forms of the gene-width forward and weight gradient (no counterpart in the reference, which gathers
  * every batch on the host: trainers/celligner2/_utils.py:188-225): the batch is rows row_index[0..M) of a RESIDENT
@@ -114,7 +116,7 @@ int c2_linear_fwd_rows(const void* A_full, int64_t lda, int64_t a_rows, const in
                        int64_t ldy, int nslab, int64_t slab_stride, const float* bias, void* stream);
 int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64_t lda, int64_t a_rows,
                          const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
-                         int64_t slab_stride, const float* alpha_dev, void* stream);
+                         int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream);
 
 /* The gene-width weight gradient (nn.Linear backward, modules.py:281-290, 467-482) with ONE operand handed over
  * TRANSPOSED, so that its reduction index (the cells of the batch) is contiguous and the 256x256 kernel reads it row-wise
@@ -127,10 +129,10 @@ int c2_linear_wgrad_rows(const void* dY, int64_t lddy, const void* A_full, int64
  * error -- use c2_linear_wgrad / c2_linear_wgrad_rows.  Results equal those entry points' up to fp32 summation order
  * inside the MFMA (same products, same K-tile order). */
 int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, int64_t ldat, int64_t M, int64_t N, int64_t K,
-                       float* dW, int64_t lddw, int nslab, int64_t slab_stride, const float* alpha_dev, void* stream);
+                       float* dW, int64_t lddw, int nslab, int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream);
 int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const void* A_full, int64_t lda, int64_t a_rows,
                             const int32_t* row_index, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
-                            int64_t slab_stride, const float* alpha_dev, void* stream);
+                            int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream);
 
 /* Block-tile edge (128 or 256) the three GEMM entry points above use for operand dtype `dtype` and an
  * [M,N] output reduced over R: callers size `nslab` from it so that a launch fills the 256 CUs.
@@ -144,6 +146,18 @@ int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void
 
 /* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
 int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);
+
+/* Several split reductions closed by one launch: out[i] = sum_s slabs[s * slab_stride + i] for i < n, per job.  The
+ * narrow layers' weight gradients of a backward pass (each a split-K GEMM into slabs) are summed together at its end
+ * instead of by one small launch each.  jobs_host: HOST array, copied by value into the launch. */
+typedef struct {
+    const float* slabs;
+    float* out;
+    int64_t slab_stride;
+    int64_t n;
+    int32_t nslab;
+} c2_slab_sum;
+int c2_sum_slabs_multi(const c2_slab_sum* jobs_host, int n_jobs, void* stream);
 /* The same for a [rows, cols] block of a wider matrix: out[r*ldo + c] = sum_s slabs[s*slab_stride + r*lds + c]. */
 int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_stride, int64_t rows, int64_t cols, int64_t lds,
                     float* out, int64_t ldo, void* stream);

@@ -1136,3 +1136,59 @@ def test_recon_nb_on_half_precision_logits(B, G):
         ops.recon_nb(lg16[:, :4096].contiguous(), x[:, :4096].contiguous(), good[:, :4096].contiguous(), sf,
                      theta[:4096].contiguous(), T(cond), 1.0 / B, loss, torch.empty(B, 4096, device=DEV, dtype=torch.bfloat16),
                      torch.empty(4096, C, device=DEV), ws, st, dbias=torch.empty(4096, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,K,nslab", [(4096, 1024, 2304, 1), (1024, 512, 2560, 3), (96, 40, 130, 1), (200, 72, 515, 2)])
+def test_weight_gradient_with_a_rank_one_term_in_its_epilogue(M, N, K, nslab):
+    """rank1_row (x) rank1_col added by the weight-gradient GEMMs' epilogue (every form; the first split of a split
+    reduction adds it once) == the same launch followed by c2_rank1_add, to fp32 rounding of one add."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).to(DEV).to(torch.bfloat16)
+    a = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    r = torch.randn(N, generator=g).to(DEV)
+    c = torch.randn((K + 7) // 8 * 8, generator=g).to(DEV)
+    alpha = torch.tensor([0.5], device=DEV)
+    shape = (nslab, N, K) if nslab > 1 else (N, K)
+
+    def close(got, want):
+        if nslab > 1:
+            got, want = got.sum(0), want.sum(0)
+        assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+
+    def ref(launch):
+        out = torch.empty(shape, device=DEV)
+        launch(out, None)
+        ops.rank1_add(out if nslab == 1 else out[0], r, c)
+        return out
+
+    forms = [lambda out, r1: ops.linear_wgrad(dy, a, out, nslab=nslab, alpha=alpha, rank1=r1)]
+    if ops.gemm_tile(torch.bfloat16, N, K, M) == 256 and M % 8 == 0:
+        at = a.t().contiguous()
+        dyt = dy.t().contiguous()
+        full = torch.randn(M + 100, K, generator=g).to(DEV).to(torch.bfloat16)
+        rows = torch.randint(0, M + 100, ((M + 63) // 64 * 64,), generator=g).to(torch.int32).to(DEV)
+        forms += [lambda out, r1: ops.linear_wgrad_bt(dy, at, out, nslab=nslab, alpha=alpha, rank1=r1),
+                  lambda out, r1: ops.linear_wgrad_rows(dy, full, rows, out, nslab=nslab, alpha=alpha, rank1=r1),
+                  lambda out, r1: ops.linear_wgrad_rows_at(dyt, full, rows, out, nslab=nslab, alpha=alpha, rank1=r1)]
+    for launch in forms:
+        out = torch.empty(shape, device=DEV)
+        launch(out, (r, c))
+        close(out, ref(launch))
+
+
+def test_sum_slabs_multi_closes_several_split_reductions_in_one_launch():
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    jobs, want = [], []
+    for S, shape in ((8, (512, 1024)), (3, (7, 13)), (2, (128, 512)), (16, (64, 64)), (1, (5,))) * 4:  # 20 jobs: two launches
+        slabs = torch.randn((S,) + shape, generator=g).to(DEV)
+        out = torch.full(shape, float("nan"), device=DEV)
+        ref = torch.empty(shape, device=DEV)
+        ops.sum_slabs(slabs, ref)
+        jobs.append((slabs, out))
+        want.append(ref)
+    ops.sum_slabs_multi(jobs)
+    for (_, out), ref in zip(jobs, want):
+        assert torch.equal(out, ref)  # the same order of additions as the single-job kernel
+    ops.sum_slabs_multi([])

@@ -139,3 +139,23 @@ def test_loader_shards_global_batches():
     for fa, fb, ff in zip(a, b, full):
         per = len(ff) // 2
         assert fa == ff[:per] and fb == ff[per:2 * per]
+
+
+def test_sharded_optimizer_refuses_to_serialise_its_partial_state():
+    """shard_optimizer=True: a rank maintains Adam's moments only inside its own chunks, so FusedAdam.state_dict() on any
+    rank would save mostly stale values without an error -- it raises instead; the all-reduce form serialises as usual."""
+    import pytest
+    import torch
+    from celligner2_amd.optim import FusedAdam
+
+    class Comm:
+        defer_last = False
+
+        def __init__(self, sharded):
+            self.sharded = sharded
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="sharded over the ranks"):
+        FusedAdam([p], grad_sync=Comm(True)).state_dict()
+    sd = FusedAdam([p], grad_sync=Comm(False)).state_dict()
+    assert sd["param_groups"][0]["lr"] == 1e-3 and FusedAdam([p]).state_dict()["state"] == {}
