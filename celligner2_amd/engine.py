@@ -125,7 +125,9 @@ class StepEngine:
         # bf16 mode: a gene-width first layer reads its input CENTRED (minus a per-gene vector c), the centre's share W c
         # goes into the bias in fp32 and (sum_b dh_b) (x) c into the weight gradient -- the same layer, but the operand that
         # is rounded to bf16 no longer carries the per-gene level all cells share (include/c2mi.h, c2_col_mean)
-        self.center_input = self.enc[0].gt == torch.bfloat16
+        import os
+        off = lambda name: os.environ.get(name) == "0"  # noqa: E731  (A/B switches: measurements and tests)
+        self.center_input = self.enc[0].gt == torch.bfloat16 and not off("C2_CENTER")
         self._center = None
         # ... and, when that input is log(1 + x) (bounded by 89: in IEEE half's range whatever the counts), the first layer's
         # FORWARD reads input and weight as IEEE halves (C2_F16: 11 significant bits instead of bf16's 8, the same matrix
@@ -133,7 +135,8 @@ class StepEngine:
         # of a bf16 encoder input put the latent heads' gradients at 1.8-3 %, beyond bf16 mode's 1e-2.  The layer's weight
         # gradient keeps bf16 operands (dh is a gradient: range matters more than digits), so the input exists in both forms.
         log_in = bool(cfg["applylog"]) and cfg["recon_loss"] != "mse"
-        self.fwd16 = torch.float16 if (self.center_input and log_in) else None
+        self.fwd16 = torch.float16 if (self.enc[0].gt == torch.bfloat16 and log_in and not off("C2_FWD16")) else None
+        self.half_logits_on = not off("C2_HALF_LOGITS")
         self.enc[-1].out_t = self.gemm_dtype("encoder.mean_encoder.weight")  # feeds the mean / log-var heads
         self.dec[-1].out_t = self.head_t
         self.cls[-1].out_t = self.gemm_dtype("classifier.classifier.0.weight")
@@ -908,7 +911,7 @@ class StepEngine:
         # as IEEE halves (2^-12 of a logit; the same mode rounds the layer's operands and dlogits to 2^-9) -- half the
         # bytes of the step's largest store, and of the loss kernel's largest read
         want_db = save and cfg["recon_loss"] == "nb" and self.p[self.head + ".bias"].requires_grad
-        half_logits = (self.head_t == torch.bfloat16 and cfg["recon_loss"] == "nb" and not wide4 and want_db
+        half_logits = (self.half_logits_on and self.head_t == torch.bfloat16 and cfg["recon_loss"] == "nb" and not wide4 and want_db
                        and d.dtype == torch.bfloat16 and ops.nb_logits_f16_ok(B, G))
         if wide4:
             logits4 = self.buf("logits4", (B, G4))
