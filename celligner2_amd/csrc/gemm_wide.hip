@@ -560,6 +560,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         for (int c = 0; c < 4; ++c)
             if (col4 + c < a.N) bv[c] = a.bias[col4 + c];
     }
+    // (half-precision output without a rank-one term, rows that start on 16 bytes: the eight-column walk below)
+    const bool half16 = a.c_f16 && !a.rowscale && ((a.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const int col8 = n0 + wn * 64 + (lane & 7) * 8;
+    float bv8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (half16 && a.bias) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (col8 + c < a.N) bv8[c] = a.bias[col8 + c];
+    }
 #pragma unroll
     for (int half = 0; half < MI / 2; ++half) {
         if constexpr (M16) {  // 16x16 tiles: lane l holds column l & 15, rows 4 (l >> 4) + 0..3
@@ -582,13 +591,39 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
                     }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (half16) {
+            // output as IEEE halves: eight columns (16 bytes) per lane, eight rows per pass -- 128-byte row segments by
+            // 16-byte stores instead of the 8-byte stores the four-column walk would make of them
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int r = rr * 4 + (lane >> 4);
-            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
-            const int row = m0 + wm * (MI * 32) + half * 64 + r;
-            if (row < a.M) {
-                store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = rr * 8 + (lane >> 3);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 7) * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 7) * 8 + 4);
+                const int row = m0 + wm * (MI * 32) + half * 64 + r;
+                if (row < a.M) {
+                    if (col8 + 8 <= a.N) {
+                        u32x4 pk;
+                        pk[0] = pack2<f16_t>(alpha * v0[0] + bv8[0], alpha * v0[1] + bv8[1]);
+                        pk[1] = pack2<f16_t>(alpha * v0[2] + bv8[2], alpha * v0[3] + bv8[3]);
+                        pk[2] = pack2<f16_t>(alpha * v1[0] + bv8[4], alpha * v1[1] + bv8[5]);
+                        pk[3] = pack2<f16_t>(alpha * v1[2] + bv8[6], alpha * v1[3] + bv8[7]);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(C) + (int64_t)row * a.ldc + col8) = pk;
+                    } else {
+                        const float bl[4] = {bv8[0], bv8[1], bv8[2], bv8[3]}, bh[4] = {bv8[4], bv8[5], bv8[6], bv8[7]};
+                        store_out4(a, C, row, col8, v0, alpha, bl, false, split == 0);
+                        store_out4(a, C, row, col8 + 4, v1, alpha, bh, false, split == 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int r = rr * 4 + (lane >> 4);
+                f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
+                const int row = m0 + wm * (MI * 32) + half * 64 + r;
+                if (row < a.M) {
+                    store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next half overwrites
