@@ -302,6 +302,60 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
         }
 }
 
+// ---- tiny problems (the classifier's 16 -> 32 -> 64 -> 30 layers, the latent heads and the decoder's first layer at the
+// reference's default batch of 128): one thread per output element, plain fp32 FMAs.  The tiled kernels spend 12-16 us on
+// such a launch (a 128x128 tile's prologue and epilogue around one or two K-steps); this one is bound by the launch itself.
+// Exact fp32 products, so it also serves the bf16x3 dtype (an approximation of the same thing).
+constexpr int64_t kTinyMacs = 1 << 21;
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a) {
+    const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+    if (idx >= (int64_t)a.M * a.N) return;
+    const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
+    const int split = blockIdx.y;
+    const int rbeg = split * a.r_per_split, rend = min(a.R, rbeg + a.r_per_split);
+    const float* A = reinterpret_cast<const float*>(a.A);
+    const float* B = reinterpret_cast<const float*>(a.B);
+    float acc = 0.f;
+    if (A_RC && B_RC && ((a.lda | a.ldb | rbeg) & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
+        const float* ar = A + (int64_t)m * a.lda;
+        const float* br = B + (int64_t)n * a.ldb;
+        int r = rbeg;
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (; r + 4 <= rend; r += 4) acc4 += *reinterpret_cast<const f32x4*>(ar + r) * *reinterpret_cast<const f32x4*>(br + r);
+        acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        for (; r < rend; ++r) acc += ar[r] * br[r];
+    } else {
+        for (int r = rbeg; r < rend; ++r) {
+            const float av = A_RC ? A[(int64_t)m * a.lda + r] : A[(int64_t)r * a.lda + m];
+            const float bv = B_RC ? B[(int64_t)n * a.ldb + r] : B[(int64_t)r * a.ldb + n];
+            acc += av * bv;
+        }
+    }
+    const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
+    float add = (a.bias ? a.bias[n] : 0.f);
+    if (a.rowscale) add = split == 0 ? add * a.rowscale[m] : 0.f;
+    float* C = a.C + (int64_t)split * a.slab_stride;
+    const float v = alpha * acc + add;
+    if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)m * a.ldc + n] = (f16_t)v;
+    else C[(int64_t)m * a.ldc + n] = v;
+}
+static bool tiny_on() {
+    static const bool on = [] { const char* e = getenv("C2_GEMM_TINY"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static bool is_tiny(int dtype, const GemmArgs& a) {
+    return tiny_on() && (dtype == C2_F32 || dtype == C2_F32X3) && (int64_t)a.M * a.N * a.R <= kTinyMacs;
+}
+static int launch_tiny(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
+    const dim3 grid((unsigned)(((int64_t)a.M * a.N + 255) / 256), nslab);
+    if (layout == 0) hipLaunchKernelGGL((gemm_tiny_kernel<true, true>), grid, dim3(256), 0, stream, a);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_tiny_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_tiny_kernel<false, false>), grid, dim3(256), 0, stream, a);
+    return 0;
+}
+
 template <typename T, bool A_RC, bool B_RC>
 static int launch_gemm(const GemmArgs& a, int nslab, hipStream_t stream) {
     constexpr int VEC = Cfg<T>::VEC;
@@ -336,6 +390,7 @@ static int gemm_dispatch(int layout, int dtype, GemmArgs a, int nslab, hipStream
     int64_t per = (a.R + nslab - 1) / nslab;
     per = (per + BK - 1) / BK * BK;
     a.r_per_split = (int)per;
+    if (layout <= 2 && is_tiny(dtype, a)) return launch_tiny(layout, a, nslab, stream);
     if (dtype == C2_F16) {  // the half-precision twin of the LDS-DMA kernels, else the register-staged kernel
         if (layout == 3) return 3;
         const int wt16 = wide_enabled() ? wide_tile_f16(dtype, a) : 0;
@@ -414,7 +469,7 @@ extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
     a.M = (int)std::min<int64_t>(M, 1 << 30);
     a.N = (int)std::min<int64_t>(N, 1 << 30);
     a.R = (int)std::min<int64_t>(R, 1 << 30);
-    if (dtype == C2_BF16X3P) return wide_tile(dtype, a);
+    if (dtype == C2_BF16X3P) return (tiny_on() && (int64_t)a.M * a.N * a.R <= kTinyMacs) ? 0 : wide_tile(dtype, a);
     const int wt = !wide_enabled() ? 0 : (dtype == C2_F16 ? wide_tile_f16(dtype, a) : wide_tile(dtype, a));
     return wt ? wt : 128;
 }
