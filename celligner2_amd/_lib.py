@@ -55,6 +55,7 @@ _SIGS = {
     "c2_linear_wgrad_rows_at": (i32, [vp, i64, vp, i64, i64, vp, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "c2_linear_wgrad_bt": (i32, [vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "c2_gemm_tile": (i32, [i32, i64, i64, i64]),
+    "c2_gemm_is_tiny": (i32, [i64, i64, i64]),
     "c2_split_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs_2d": (i32, [vp, i32, i64, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),

@@ -307,32 +307,40 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 // such a launch (a 128x128 tile's prologue and epilogue around one or two K-steps); this one is bound by the launch itself.
 // Exact fp32 products, so it also serves the bf16x3 dtype (an approximation of the same thing).
 constexpr int64_t kTinyMacs = 1 << 21;
+// Eight lanes share one output element: each walks every eighth reduction index (so 16 384 outputs are 2048 waves, not 256,
+// and the serial chain of a 128-long reduction is 16 loads deep, not 128), then three shuffle steps add the eight partial sums.
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a) {
-    const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
-    if (idx >= (int64_t)a.M * a.N) return;
-    const int m = (int)(idx / a.N), n = (int)(idx - (int64_t)m * a.N);
+    const int64_t idx = (blockIdx.x * 256ll + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const bool live = idx < (int64_t)a.M * a.N;
+    const int m = live ? (int)(idx / a.N) : 0, n = live ? (int)(idx - (int64_t)m * a.N) : 0;
     const int split = blockIdx.y;
     const int rbeg = split * a.r_per_split, rend = min(a.R, rbeg + a.r_per_split);
     const float* A = reinterpret_cast<const float*>(a.A);
     const float* B = reinterpret_cast<const float*>(a.B);
-    float acc = 0.f;
-    if (A_RC && B_RC && ((a.lda | a.ldb | rbeg) & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
-        const float* ar = A + (int64_t)m * a.lda;
-        const float* br = B + (int64_t)n * a.ldb;
-        int r = rbeg;
-        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-        for (; r + 4 <= rend; r += 4) acc4 += *reinterpret_cast<const f32x4*>(ar + r) * *reinterpret_cast<const f32x4*>(br + r);
-        acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-        for (; r < rend; ++r) acc += ar[r] * br[r];
-    } else {
-        for (int r = rbeg; r < rend; ++r) {
-            const float av = A_RC ? A[(int64_t)m * a.lda + r] : A[(int64_t)r * a.lda + m];
-            const float bv = B_RC ? B[(int64_t)n * a.ldb + r] : B[(int64_t)r * a.ldb + n];
-            acc += av * bv;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (live) {
+        int r = rbeg + sub;
+        for (; r + 8 < rend; r += 16) {  // two independent chains
+            const float a0 = A_RC ? A[(int64_t)m * a.lda + r] : A[(int64_t)r * a.lda + m];
+            const float b0 = B_RC ? B[(int64_t)n * a.ldb + r] : B[(int64_t)r * a.ldb + n];
+            const float a1 = A_RC ? A[(int64_t)m * a.lda + r + 8] : A[(int64_t)(r + 8) * a.lda + m];
+            const float b1 = B_RC ? B[(int64_t)n * a.ldb + r + 8] : B[(int64_t)(r + 8) * a.ldb + n];
+            acc0 += a0 * b0;
+            acc1 += a1 * b1;
+        }
+        if (r < rend) {
+            const float a0 = A_RC ? A[(int64_t)m * a.lda + r] : A[(int64_t)r * a.lda + m];
+            const float b0 = B_RC ? B[(int64_t)n * a.ldb + r] : B[(int64_t)r * a.ldb + n];
+            acc0 += a0 * b0;
         }
     }
+    float acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (!live || sub != 0) return;
     const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
     float add = (a.bias ? a.bias[n] : 0.f);
     if (a.rowscale) add = split == 0 ? add * a.rowscale[m] : 0.f;
@@ -349,7 +357,7 @@ static bool is_tiny(int dtype, const GemmArgs& a) {
     return tiny_on() && (dtype == C2_F32 || dtype == C2_F32X3) && (int64_t)a.M * a.N * a.R <= kTinyMacs;
 }
 static int launch_tiny(int layout, const GemmArgs& a, int nslab, hipStream_t stream) {
-    const dim3 grid((unsigned)(((int64_t)a.M * a.N + 255) / 256), nslab);
+    const dim3 grid((unsigned)(((int64_t)a.M * a.N * 8 + 255) / 256), nslab);  // eight lanes per output element
     if (layout == 0) hipLaunchKernelGGL((gemm_tiny_kernel<true, true>), grid, dim3(256), 0, stream, a);
     else if (layout == 1) hipLaunchKernelGGL((gemm_tiny_kernel<true, false>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_tiny_kernel<false, false>), grid, dim3(256), 0, stream, a);
@@ -464,12 +472,16 @@ static bool gemm_args_ok(int dtype, int64_t M, int64_t N, int64_t K, int nslab) 
            M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31);
 }
 
+extern "C" int c2_gemm_is_tiny(int64_t M, int64_t N, int64_t R) {
+    return (tiny_on() && M >= 0 && N >= 0 && R >= 0 && M * N * R <= kTinyMacs) ? 1 : 0;
+}
+
 extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
     GemmArgs a{};
     a.M = (int)std::min<int64_t>(M, 1 << 30);
     a.N = (int)std::min<int64_t>(N, 1 << 30);
     a.R = (int)std::min<int64_t>(R, 1 << 30);
-    if (dtype == C2_BF16X3P) return (tiny_on() && (int64_t)a.M * a.N * a.R <= kTinyMacs) ? 0 : wide_tile(dtype, a);
+    if (dtype == C2_BF16X3P) return wide_tile(dtype, a);
     const int wt = !wide_enabled() ? 0 : (dtype == C2_F16 ? wide_tile_f16(dtype, a) : wide_tile(dtype, a));
     return wt ? wt : 128;
 }

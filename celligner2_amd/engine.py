@@ -458,7 +458,7 @@ class StepEngine:
         """Operand pair of one GEMM ([M,N] output reduced over R): planes when both are fp32 in bf16x3 mode and the
         shape allows, else unchanged.  wx / wy: parameter name when that operand is a weight.  Returns (x, y, planes)."""
         if not (self.x3 and x.dtype == F32 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous()
-                and ops.planes_ok(M, N, R, (x.shape[1], y.shape[1]))):
+                and not ops.gemm_is_tiny(M, N, R) and ops.planes_ok(M, N, R, (x.shape[1], y.shape[1]))):
             return x, y, False
         px = self._wplanes_of(wx) if wx else self._planes_of(x)
         py = self._wplanes_of(wy) if wy else self._planes_of(y)
@@ -1092,7 +1092,8 @@ class StepEngine:
         # followed by one slab from the classifier branch; the reparameterisation backward sums them
         H0 = self.p[self.dec[0].w].shape[0]
         nz = ops.pick_nslab(B, L, H0, self.dec[0].gt, self.x3,
-                            planes=self.x3 and self.dec[0].gt == F32 and ops.planes_ok(B, L, H0, (H0, L)))
+                            planes=(self.x3 and self.dec[0].gt == F32 and not ops.gemm_is_tiny(B, L, H0)
+                                    and ops.planes_ok(B, L, H0, (H0, L))))
         dz_all = self.buf("dz.all", (nz + n_cls_slab, B, L))
         on_y = cfg["use_mmd"] and cfg["mmd_on"] != "z"
         self._block_bwd(self.dec[0], dd, self._dec_in[0], cond, masks, True, out_slabs=dz_all[0:nz],

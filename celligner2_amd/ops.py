@@ -73,6 +73,11 @@ def gemm_tile(dtype, M, N, R, x3=False, planes=False):
     return int(lib.c2_gemm_tile(code, M, N, R))
 
 
+def gemm_is_tiny(M, N, R):
+    """An fp32-operand problem this small runs on the one-thread-per-output kernel (no planes, no tiles)."""
+    return bool(lib.c2_gemm_is_tiny(M, N, R))
+
+
 def planes_ok(M, N, R, lds=()):
     """Can an [M,N] = sum over R GEMM run on bf16 planes (LDS-DMA kernel)?  lds: the operands' leading dimensions."""
     return gemm_tile(None, M, N, R, planes=True) > 0 and all(int(x) % 8 == 0 for x in lds)

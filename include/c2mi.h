@@ -139,6 +139,9 @@ int c2_linear_wgrad_rows_at(const void* dYt, int64_t lddyt, const void* A_full, 
  * 0 = this dtype cannot take the shape (C2_BF16X3P only).
  * (No counterpart in the reference: torch picks its own BLAS blocking.) */
 int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R);
+/* 1 when an [M,N] = sum over R problem with fp32 operands (C2_F32 / C2_F32X3) runs on the one-thread-per-output kernel (at
+ * most 2^21 multiply-adds): a caller that would split such operands into bf16 planes (C2_BF16X3P) should not. */
+int c2_gemm_is_tiny(int64_t M, int64_t N, int64_t R);
 
 /* fp32 [rows, cols] -> two bf16 planes dst[0] = hi = bf16(x), dst[1] = lo = bf16(x - hi); dst is [2][rows][ldd].
  * Producer side of C2_BF16X3P (no counterpart in the reference, which multiplies in fp32). */
