@@ -12,6 +12,7 @@ Precision modes
 """
 from __future__ import annotations
 
+import contextlib
 from collections import OrderedDict
 
 import torch
@@ -137,6 +138,15 @@ class StepEngine:
         log_in = bool(cfg["applylog"]) and cfg["recon_loss"] != "mse"
         self.fwd16 = torch.float16 if (self.enc[0].gt == torch.bfloat16 and log_in and not off("C2_FWD16")) else None
         self.half_logits_on = not off("C2_HALF_LOGITS")
+        # The backward pass is two chains: activation gradients (tail, input-gradient GEMM, the next layer's tail ...: each
+        # waits for the one before) and parameter gradients (bias / condition column sums, weight-gradient GEMM, slab sums:
+        # nothing but the optimizer waits for them).  The second chain is queued on a stream of its own (one process, no
+        # gradient exchange), so its launches fill the compute units the narrow layers of the first chain leave idle; a
+        # captured step keeps the two branches.  C2_SIDE=0: one stream.
+        self.side_on = os.environ.get("C2_SIDE") == "1"
+        self.side_level = int(os.environ.get("C2_SIDE_LEVEL", "1"))
+        self._wstream = None
+        self._side_used = False
         self.enc[-1].out_t = self.gemm_dtype("encoder.mean_encoder.weight")  # feeds the mean / log-var heads
         self.dec[-1].out_t = self.head_t
         self.cls[-1].out_t = self.gemm_dtype("classifier.classifier.0.weight")
@@ -633,6 +643,26 @@ class StepEngine:
             ops.sum_slabs_2d(slabs, g[:, cut:])
         return True
 
+    @contextlib.contextmanager
+    def _param_side(self, level=2):
+        """Queue what runs inside on the parameter-gradient stream, after everything the current stream holds so far.
+        level: C2_SIDE_LEVEL at or above which this site forks (1: the output layer's gene-width gradients only)."""
+        if not self.side_on or self.comm is not None or level > self.side_level:
+            yield
+            return
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(self.dev)
+        self._wstream.wait_stream(torch.cuda.current_stream(self.dev))
+        self._side_used = True
+        with torch.cuda.stream(self._wstream):
+            yield
+
+    def _join_side(self):
+        """The current stream waits for the parameter-gradient stream (end of a backward pass)."""
+        if self._side_used:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wstream)
+            self._side_used = False
+
     def _batch_center(self, x, log_in):
         """Centre of a batch handed in as tensors: the per-gene mean of its own encoder input (any vector is exact; the
         mean leaves the smallest operand).  [G rounded up to 8] fp32, pad zero."""
@@ -736,24 +766,26 @@ class StepEngine:
         need_w = self.p[blk.w].requires_grad
         need_b = blk.b is not None and self.p[blk.b].requires_grad
         need_c = blk.wc is not None and self.p[blk.wc].requires_grad
-        # a centred first layer: dW = dh^T (x - c) + (sum_b dh_b) (x) c -- the column sums of dh (the bias gradient) come
+        # the activation gradient first (the chain every later launch of this pass waits for) ...
+        if need_da:
+            K = self.p[blk.w].shape[1]
+            if out_slabs is None:
+                out_slabs = self.buf(blk.name + ".da", (self._dgrad_nslab(dh, blk.w), B, K))
+            self._dgrad(dh, blk.w, out_slabs)
+        # ... then the parameter gradients, which only the optimizer waits for.
+        # A centred first layer: dW = dh^T (x - c) + (sum_b dh_b) (x) c -- the column sums of dh (the bias gradient) come
         # first, the rank-one term rides in the weight-gradient GEMM's epilogue
         centred = blk is self.enc[0] and self._center is not None and need_w
-        db = None
-        if need_b or need_c or centred:
-            C = cond.shape[1] if need_c else 0
-            ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
-            db = self.gbuf(blk.b) if need_b else (self.buf("enc0.dhsum", (H,)) if centred else None)
-            ops.bias_cond_grad(dh, cond if need_c else None, db, self.gbuf(blk.wc) if need_c else None, ws)
-        if need_w:
-            self._wgrad(dh, a_in, blk.w, rank1=(db, self._center) if centred else None)
-        if not need_da:
-            return None
-        K = self.p[blk.w].shape[1]
-        if out_slabs is None:
-            out_slabs = self.buf(blk.name + ".da", (self._dgrad_nslab(dh, blk.w), B, K))
-        self._dgrad(dh, blk.w, out_slabs)
-        return out_slabs
+        with self._param_side():
+            db = None
+            if need_b or need_c or centred:
+                C = cond.shape[1] if need_c else 0
+                ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
+                db = self.gbuf(blk.b) if need_b else (self.buf("enc0.dhsum", (H,)) if centred else None)
+                ops.bias_cond_grad(dh, cond if need_c else None, db, self.gbuf(blk.wc) if need_c else None, ws)
+            if need_w:
+                self._wgrad(dh, a_in, blk.w, rank1=(db, self._center) if centred else None)
+        return out_slabs if need_da else None
 
     def _partition(self, cond_all, status):
         """Partition ids of the batch's condition rows + the pair-weight table of the MMD (losses.py:202-249)."""
@@ -1049,6 +1081,7 @@ class StepEngine:
             return self._backward(g, cfg, B, cond, masks)
         finally:
             self._slab_jobs = None
+            self._join_side()  # (also on an error: nothing may stay queued beside the caller's stream)
 
     def _backward(self, g, cfg, B, cond, masks):
         gr, gk, gm, gc = g[0:1], g[1:2], g[2:3], g[3:4]
@@ -1057,30 +1090,32 @@ class StepEngine:
         G = dlogits.shape[1]
         # ---- decoder output layer
         hw, hb = self.head + ".weight", self.head + ".bias"
-        if rq(hw):
-            self._wgrad(dlogits, self._dlast, hw, alpha=gr)
-        if rq(hb):
-            if self._ws.get("dbias.unit") is not None:  # (NB: formed by the loss kernel)
-                ops.scale(self._ws["dbias.unit"], gr, self.gbuf(hb))
-            else:
-                ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
-                ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
         H1 = self.p[hw].shape[1]
         ns1 = self._dgrad_nslab(dlogits, hw)
         ns2 = self._dgrad_nslab(dlogits, self.head2 + ".weight") if self.head2 else 0
         dd = self.buf("dhead.da", (ns1 + ns2, B, H1))
         self._dgrad(dlogits, hw, dd[:ns1], alpha=gr)
-        if self.head2:  # ZINB: the dropout head's gradients; its dgrad lands in further slabs of the same sum
+        if self.head2:  # ZINB: the dropout head's input gradient lands in further slabs of the same sum
             dpi = self._ws["dpi"]
             h2w, h2b = self.head2 + ".weight", self.head2 + ".bias"
-            if rq(h2w):
-                self._wgrad(dpi, self._dlast, h2w, alpha=gr)
-            if rq(h2b):
-                ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
-                ops.bias_cond_grad(dpi, None, self.gbuf(h2b), None, ws, alpha=gr)
             self._dgrad(dpi, h2w, dd[ns1:], alpha=gr)
-        if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
-            ops.scale(self._ws["dtheta.unit"], gr, self.gbuf("theta"))
+        with self._param_side(1):
+            if rq(hw):
+                self._wgrad(dlogits, self._dlast, hw, alpha=gr)
+            if rq(hb):
+                if self._ws.get("dbias.unit") is not None:  # (NB: formed by the loss kernel)
+                    ops.scale(self._ws["dbias.unit"], gr, self.gbuf(hb))
+                else:
+                    ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+                    ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
+            if self.head2:
+                if rq(h2w):
+                    self._wgrad(dpi, self._dlast, h2w, alpha=gr)
+                if rq(h2b):
+                    ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+                    ops.bias_cond_grad(dpi, None, self.gbuf(h2b), None, ws, alpha=gr)
+            if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
+                ops.scale(self._ws["dtheta.unit"], gr, self.gbuf("theta"))
         self._build_arena()
         self._reduce_bucket(0)  # overlaps everything below
         # ---- decoder hidden blocks, then the first block (mmd_on='y' enters at its output)
@@ -1102,13 +1137,14 @@ class StepEngine:
         if n_cls_slab:
             du = self._ws["du"]
             cw, cb = "classifier.classifier.0.weight", "classifier.classifier.0.bias"
-            if rq(cw):
-                self._wgrad(du, self._clast, cw, alpha=gc)
-            if rq(cb):
-                ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
-                ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
             dc = self.buf("dcls.da", (1, B, self._clast.shape[1]))
             self._dgrad(du, cw, dc, alpha=gc)
+            with self._param_side():
+                if rq(cw):
+                    self._wgrad(du, self._clast, cw, alpha=gc)
+                if rq(cb):
+                    ws = self.buf("bcg.ws.P", (ops.bias_cond_grad_ws(B, du.shape[1], 0),))
+                    ops.bias_cond_grad(du, None, self.gbuf(cb), None, ws, alpha=gc)
             for i in range(len(self.cls) - 1, 0, -1):
                 dc = self._block_bwd(self.cls[i], dc, self._cls_in[i], None, masks, True)
             self._block_bwd(self.cls[0], dc, self._cls_in[0], None, masks, True, out_slabs=dz_all[nz:nz + 1])
@@ -1124,30 +1160,33 @@ class StepEngine:
             ops.reparam_kl_bwd(dz_all, mu, lv, self._eps, inv_Bg, cfg["use_own_kl"], gk, dml[:, :L], dml[:, L:],
                                extra=xz, extra_scale=xs)
             wn, bn_ = [h + ".weight" for h in self.HEADS], [h + ".bias" for h in self.HEADS]
-            if rq(wn[0]):  # one [2L, H] view over the two (adjacent) gradient tensors
-                g0 = self.gbuf(wn[0])
-                self.gbuf(wn[1])
-                g = self.grad_flat[g0.storage_offset():g0.storage_offset() + 2 * L * Hk].view(2 * L, Hk)
-                self._wgrad(dml, henc, None, g=g)
-            if rq(bn_[0]):
-                b0 = self.gbuf(bn_[0])
-                self.gbuf(bn_[1])
-                ws = self.buf("bcg.ws.2L", (ops.bias_cond_grad_ws(B, 2 * L, 0),))
-                ops.bias_cond_grad(dml, None, self.grad_flat[b0.storage_offset():b0.storage_offset() + 2 * L], None, ws)
             da = self.buf("dheads.da.cat", (self._dgrad_nslab(dml, self.HEADW), B, Hk))
             self._dgrad(dml, self.HEADW, da)
+            with self._param_side():
+                if rq(wn[0]):  # one [2L, H] view over the two (adjacent) gradient tensors
+                    g0 = self.gbuf(wn[0])
+                    self.gbuf(wn[1])
+                    g = self.grad_flat[g0.storage_offset():g0.storage_offset() + 2 * L * Hk].view(2 * L, Hk)
+                    self._wgrad(dml, henc, None, g=g)
+                if rq(bn_[0]):
+                    b0 = self.gbuf(bn_[0])
+                    self.gbuf(bn_[1])
+                    ws = self.buf("bcg.ws.2L", (ops.bias_cond_grad_ws(B, 2 * L, 0),))
+                    ops.bias_cond_grad(dml, None, self.grad_flat[b0.storage_offset():b0.storage_offset() + 2 * L], None, ws)
         else:
             dml = self.buf("dmulv", (2, B, L), self.gemm_dtype("encoder.mean_encoder.weight"))
             ops.reparam_kl_bwd(dz_all, mu, lv, self._eps, inv_Bg, cfg["use_own_kl"], gk, dml[0], dml[1], extra=xz,
                                extra_scale=xs)
             da = self.buf("dheads.da", (2, B, Hk))
             for k, nm in enumerate(self.HEADS):
-                if rq(nm + ".weight"):
-                    self._wgrad(dml[k], henc, nm + ".weight")
-                if rq(nm + ".bias"):
-                    ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
-                    ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
                 self._dgrad(dml[k], nm + ".weight", da[k:k + 1])
+            with self._param_side():
+                for k, nm in enumerate(self.HEADS):
+                    if rq(nm + ".weight"):
+                        self._wgrad(dml[k], henc, nm + ".weight")
+                    if rq(nm + ".bias"):
+                        ws = self.buf("bcg.ws.L", (ops.bias_cond_grad_ws(B, L, 0),))
+                        ops.bias_cond_grad(dml[k], None, self.gbuf(nm + ".bias"), None, ws)
         # ---- encoder blocks
         need = self._first_trainable_enc()
         for i in range(len(self.enc) - 1, -1, -1):
@@ -1156,7 +1195,9 @@ class StepEngine:
             if i == 0:
                 self._reduce_bucket(1)  # overlaps the gene-width wgrad of encoder L0
             da = self._block_bwd(self.enc[i], da, self._enc_in[i], cond, masks, need_da=(i > need))
-        self._flush_slab_sums()
+        with self._param_side():
+            self._flush_slab_sums()
+        self._join_side()
         if need > 0:
             self._reduce_bucket(1)
         self._reduce_bucket(2)

@@ -439,41 +439,35 @@ class Celligner2(nn.Module):
                 for n, s in shapes[nh:] + cls_shapes:
                     masks[n] = cpu_mask(s)
         else:
-            eps = torch.randn(W * B, self.latent_dim, device=device)
-            if W > 1:
-                eps = eps[own].contiguous()
-            allshapes = shapes + cls_shapes
-            if training and allshapes:
-                # every mask of the step from one Philox launch into one flat buffer (16-byte aligned slices); the
-                # counter range of a step is cut into one stretch per rank
-                sizes = [(s[0] * s[1] + 15) // 16 * 16 for _, s in allshapes]
-                total = sum(sizes)
+            # every mask of the step and eps from ONE launch (c2_noise_dev), whose Philox counter lives in device memory and is
+            # advanced by the launch itself: a step replayed as a HIP graph draws fresh noise, and no torch generator is
+            # consumed (a replay then needs none of torch's generator bookkeeping launches).  Masks into one flat buffer
+            # (16-byte aligned slices); the counter range of a step is cut into one stretch per rank.
+            allshapes = (shapes + cls_shapes) if training else []
+            sizes = [(s[0] * s[1] + 15) // 16 * 16 for _, s in allshapes]
+            total = sum(sizes)
+            flat = None
+            if total:
                 # (one buffer per batch shape, ONE counter for all of them: a short last batch neither evicts the
                 # full-size buffer nor restarts the stream)
                 bufs = self.__dict__.setdefault("_mask_bufs", {})
                 flat = bufs.get((total, device))
                 if flat is None:
                     flat = bufs[(total, device)] = torch.empty(total, dtype=torch.uint8, device=device)
-                if "_mask_seed" not in self.__dict__:
-                    self.__dict__["_mask_seed"] = torch.initial_seed()
-                    self.__dict__["_mask_offset"] = 0
-                ctr = self.__dict__.get("_mask_counter")
-                if ctr is not None:
-                    # (data-parallel: the counter holds the same value on every rank; rank r reads its stretch of the step's
-                    # range through the lead, exactly the host-counter form below)
-                    if ctr is False or ctr.device != device:
-                        ctr = self.__dict__["_mask_counter"] = torch.tensor(
-                            [self.__dict__["_mask_offset"]], dtype=torch.int64, device=device)
-                    ops.dropout_masks_dev(flat, self.dr_rate, self.__dict__["_mask_seed"], ctr, W * (total // 16),
-                                          lead=r * (total // 16))
-                else:
-                    ops.dropout_masks(flat, self.dr_rate, self.__dict__["_mask_seed"],
-                                      self.__dict__["_mask_offset"] + r * (total // 16))
-                    self.__dict__["_mask_offset"] += W * (total // 16)
-                o = 0
-                for (n, s), sz in zip(allshapes, sizes):
-                    masks[n] = flat[o:o + s[0] * s[1]].view(s)
-                    o += sz
+            if "_mask_seed" not in self.__dict__:
+                self.__dict__["_mask_seed"] = torch.initial_seed()
+            state = self.__dict__.get("_noise_state")
+            if state is None or state.device != device:
+                first = 0 if state is None else int(state[0].item())
+                state = self.__dict__["_noise_state"] = torch.tensor([first, 0], dtype=torch.int64, device=device)
+            L = self.latent_dim
+            eps = torch.empty(B, L, device=device)
+            ops.noise_dev(flat, self.dr_rate if total else 0.0, eps, r * B * L, self.__dict__["_mask_seed"], state,
+                          advance=max(W * (total // 16), (W * B * L + 3) // 4), lead=r * (total // 16))
+            o = 0
+            for (n, s), sz in zip(allshapes, sizes):
+                masks[n] = flat[o:o + s[0] * s[1]].view(s)
+                o += sz
         return eps, masks
 
     # ------------------------------------------------------------------ the reference's API
@@ -578,15 +572,8 @@ class Celligner2(nn.Module):
             self.__dict__["_loss_sums"] = sums
 
     def device_noise_counter(self, on):
-        """rng_mode "device": keep the dropout masks' Philox counter in device memory (advanced by the mask launch
-        itself), so that a replayed step draws fresh masks.  Switching back reads it (one sync).  Same masks either
-        way: only where the counter lives changes."""
-        if on and self.__dict__.get("_mask_counter") is None:
-            self.__dict__["_mask_counter"] = False  # created by the first draw, from the host's count
-        elif not on and self.__dict__.get("_mask_counter") is not None:
-            c = self.__dict__.pop("_mask_counter")
-            if c is not False:
-                self.__dict__["_mask_offset"] = int(c.item())
+        """rng_mode "device" keeps its Philox counter in device memory whether or not the step is captured (c2_noise_dev
+        advances it); kept for callers of earlier versions, where the counter moved between host and device."""
 
     def sampling(self, mu, log_var):
         """othermodels/base/_base.py:464-480."""

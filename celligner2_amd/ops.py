@@ -811,10 +811,29 @@ def dropout_masks_dev(out, p_drop, seed, offset_dev, advance, lead=0):
     the counter is advanced by `advance` after the masks are drawn."""
     L.require_gpu(out, offset_dev)
     assert out.dtype == torch.uint8 and out.is_contiguous()
-    assert offset_dev.dtype == torch.int64 and offset_dev.numel() == 1
+    assert offset_dev.dtype == torch.int64 and offset_dev.numel() >= 1
     check(lib.c2_dropout_masks_dev(ptr(out), out.numel(), float(p_drop), int(seed) & (2 ** 64 - 1), ptr(offset_dev),
                                    int(lead), int(advance), stream()))
     return out
+
+
+def noise_dev(masks, p_drop, eps, eps_first, seed, state, advance, lead=0):
+    """One launch for a step's noise with the Philox counter in device memory (c2_noise_dev): keep-masks into the flat
+    uint8 buffer `masks` (or None), standard normals into the fp32 tensor `eps` (or None; its elements are elements
+    eps_first.. of the global batch's matrix), then state[0] += advance.  state: int64 [2] = (counter, 0)."""
+    L.require_gpu(state)
+    assert state.dtype == torch.int64 and state.numel() == 2 and state.is_contiguous()
+    assert masks is None or (masks.dtype == torch.uint8 and masks.is_contiguous())
+    assert eps is None or (eps.dtype == torch.float32 and eps.is_contiguous())
+    check(lib.c2_noise_dev(ptr(masks) if masks is not None else None, masks.numel() if masks is not None else 0,
+                           float(p_drop), ptr(eps) if eps is not None else None, eps.numel() if eps is not None else 0,
+                           int(eps_first), int(seed) & (2 ** 64 - 1), ptr(state), int(lead), int(advance), stream()))
+
+
+def graph_launch(graph_exec):
+    """Launch an instantiated HIP graph (the integer handle torch.cuda.CUDAGraph.raw_cuda_graph_exec() returns) on the
+    current stream."""
+    check(lib.c2_graph_launch(int(graph_exec), stream()))
 
 
 def decoder_output(logits, mode):

@@ -22,6 +22,7 @@ data-parallel step costs the host what the single-GPU step costs (one graph laun
 """
 from __future__ import annotations
 
+import os
 import sys
 import time
 from collections import defaultdict
@@ -29,6 +30,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+from . import ops
 from .dataset import make_dataset
 from .optim import FusedAdam
 
@@ -225,6 +227,7 @@ class _StepGraph:
     def __init__(self, trainer):
         self.trainer, self.graph, self.calls, self.count = trainer, None, 0, 0
         self.refused = None  # why the capture was given up (data-parallel only), else None
+        self.raw = None      # hipGraphExec_t of the captured step
         dev = trainer.device
         self.alpha = trainer.calc_alpha_coeff()
         self.weights = torch.tensor([1.0, self.alpha, 1.0, 1.0], dtype=torch.float32, device=dev)
@@ -285,9 +288,17 @@ class _StepGraph:
             if graph is not None:
                 t.optimizer.captured()  # recorded, not run: the replay below performs this step
                 self.graph, self.engine = graph, engine
+                # The step consumes no torch generator (rng="device": its noise is c2_noise_dev's, counter in device memory),
+                # so a replay is hipGraphLaunch and nothing else; CUDAGraph.replay() first refreshes the seed / offset
+                # tensors of every generator registered with the capture -- two fill launches per step that nothing reads.
+                # (C2_GRAPH_RAW=0: replay through torch.)
+                self.raw = graph.raw_cuda_graph_exec() if os.environ.get("C2_GRAPH_RAW") != "0" else None
         if self.graph is not None:
             t.optimizer.sync_hyper()
-            self.graph.replay()
+            if self.raw:
+                ops.graph_launch(self.raw)
+            else:
+                self.graph.replay()
             t.optimizer.replayed()
             t.graph_replays += 1
         else:
@@ -309,7 +320,7 @@ class _StepGraph:
         model = self.trainer.model
         model.loss_sums(None)
         model.device_noise_counter(False)
-        self.graph = None
+        self.graph = self.raw = None
 
 
 class Trainer:

@@ -445,6 +445,21 @@ int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* str
 int c2_dropout_masks_dev(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t* offset_dev, uint64_t lead,
                          uint64_t advance, void* stream);
 
+/* All the noise of one training step in one launch, for steps replayed as a HIP graph (no counterpart in the reference, whose
+ * noise comes from torch's generator: nn.Dropout in modules.py:304-306, 448-450 and celligner2.py:248 `eps = torch.randn_like`):
+ * the dropout keep-masks exactly as c2_dropout_masks_dev draws them (n_mask bytes from counter value state[0] + lead), the
+ * standard normals of the reparameterisation (eps[0 .. n_eps) = elements eps_first .. of the GLOBAL batch's [rows, latent]
+ * matrix: element e is Box-Muller word pair e % 4 of the Philox block at counter state[0] + e / 4 under a second key, so
+ * a rank's rows equal the rows one process draws), and the counter's advance, done by the block that is last to
+ * read the counter (state[0] += advance; state[1], the count of blocks that have read it, returns to 0).  state: two 64-bit words in device memory,
+ * state[1] zero before the first call.  Either part may be empty (n_mask 0 / n_eps 0). */
+int c2_noise_dev(uint8_t* masks, int64_t n_mask, float p_drop, float* eps, int64_t n_eps, uint64_t eps_first, uint64_t seed,
+                 uint64_t* state, uint64_t lead, uint64_t advance, void* stream);
+
+/* Launch an instantiated HIP graph (hipGraphExec_t) on a stream: hipGraphLaunch.  For hosts that captured a step through
+ * another runtime's wrapper and replay it themselves (no counterpart in the reference). */
+int c2_graph_launch(void* graph_exec, void* stream);
+
 /* Output activation of the decoder on the inference path -- Decoder.forward (celligner2/model/modules.py:467-482) as
  * Celligner2.reconstructLatent returns it (celligner2/model/celligner2.py:411-420): mode 0 = nn.Softmax(dim=-1) over the
  * genes (NB / ZINB mean head), mode 1 = nn.ReLU (MSE head).  logits [B,G] fp32 (row stride ldl) -> out [B,G] fp32. */

@@ -131,6 +131,48 @@ def test_dropout_masks_with_a_device_counter_continue_the_host_counters_stream()
     assert abs(float(b.float().mean()) - (1 - 77 / 256)) < 0.02  # thresh8 = round(0.3*256) = 77
 
 
+def test_one_launch_noise_masks_normals_and_counter():
+    """c2_noise_dev: masks equal to c2_dropout_masks at the same counter values; eps standard normal, fresh on every call,
+    a rank's rows equal to the same rows of the one-process draw; the counter advanced by the launch itself."""
+    from celligner2_amd import ops
+    n = 16 * 700 + 9
+    B, L, W = 96, 26, 4   # (B * L not a multiple of 4: ranks' element ranges start inside a Philox block)
+    adv_m = (n + 15) // 16
+    adv = max(W * adv_m, (W * B * L + 3) // 4)
+    ref = torch.empty(n, dtype=torch.uint8, device="cuda")
+    state = torch.tensor([777, 0], dtype=torch.int64, device="cuda")
+    whole = torch.empty(W * B, L, device="cuda")
+    seen = []
+    for k in range(3):
+        # one process over the global batch ...
+        st1 = torch.tensor([777 + k * adv, 0], dtype=torch.int64, device="cuda")
+        ops.noise_dev(None, 0.0, whole, 0, 99, st1, advance=adv)
+        assert st1.tolist() == [777 + (k + 1) * adv, 0]
+        # ... and rank 2 of 4 (its own state advances as every rank's does)
+        m = torch.empty(n, dtype=torch.uint8, device="cuda")
+        e = torch.empty(B, L, device="cuda")
+        ops.noise_dev(m, 0.3, e, 2 * B * L, 99, state, advance=adv, lead=2 * adv_m)
+        ops.dropout_masks(ref, 0.3, 99, 777 + k * adv + 2 * adv_m)
+        assert torch.equal(m, ref), k
+        assert torch.equal(e, whole[2 * B:3 * B]), k
+        seen.append(whole.clone())
+    assert state.tolist() == [777 + 3 * adv, 0]
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    # the normals: moments of 2^20 draws, and no correlation between neighbours (the two Box-Muller outputs of a pair)
+    big = torch.empty(1 << 20, device="cuda")
+    ops.noise_dev(None, 0.0, big, 0, 5, torch.tensor([0, 0], dtype=torch.int64, device="cuda"), advance=1 << 18)
+    d = big.double()
+    assert abs(float(d.mean())) < 4e-3 and abs(float(d.var()) - 1) < 6e-3
+    assert abs(float((d ** 3).mean())) < 2e-2 and abs(float((d ** 4).mean()) - 3) < 5e-2
+    assert abs(float((d[0::2] * d[1::2]).mean())) < 4e-3 and abs(float((d[:-4] * d[4:]).mean())) < 4e-3
+    assert float(d.abs().max()) < 6.0 and bool(torch.isfinite(big).all())
+    # a launch with nothing to draw still advances; an empty call with no advance is a no-op
+    st = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    ops.noise_dev(None, 0.0, None, 0, 1, st, advance=7)
+    ops.noise_dev(None, 0.0, None, 0, 1, st, advance=0)
+    assert st.tolist() == [12, 0]
+
+
 @pytest.mark.parametrize("shadow", [False, True])
 def test_adam_with_device_state_is_the_host_scalar_step(shadow):
     from celligner2_amd import ops
