@@ -83,7 +83,7 @@ def synth_dataset(cfg, device, seed=2020):
     sf = X.sum(1)
     if cfg.get("recon") == "mse":  # the MSE configurations feed log-transformed expression
         X = torch.log1p(X)
-    return DeviceDataset.from_tensors(X, sf, good, cond, pred, minweight=0.2)
+    return DeviceDataset.from_tensors(X, sf, good, cond, pred, minweight=0.2, repitch=True)
 
 
 def _cpu_model():

@@ -105,6 +105,8 @@ _SIGS = {
     "c2_transpose_bf16": (i32, [vp, i64, i64, i64, vp, i64, vp]),
     "c2_gather_rows": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp,
                              vp, i64, vp, vp, i64, vp]),
+    "c2_gather_rows_ld": (i32, [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32,
+                                i64, i32, vp, vp, vp, i64, vp, vp, i64, vp]),
     "c2_combine_losses": (i32, [vp, f32, f32, f32, f32, vp, vp]),
     "c2_defer_loss_sums": (i32, [i32]),
     "c2_scale4": (i32, [vp, f32, f32, f32, f32, vp, vp]),

@@ -665,7 +665,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     TX* __restrict__ xin_out, int64_t ldxin, int apply_log, int vec_ok, int vec_xin,
     const float* __restrict__ rowconst, float* __restrict__ rowconst_out, int32_t* __restrict__ idx32_out,
     int64_t n, int64_t n_pad, const float* __restrict__ center, bf16_t* __restrict__ xin2_out, int64_t ldxin2,
-    int vec_xin2) {
+    int vec_xin2, int64_t ldX, int64_t ldg, int64_t ldxo, int64_t ldgo, int64_t Gw) {
+    // ldX / ldg / ldxo / ldgo: row pitches of X, goodloc, x_out, goodloc_out.  Gw: the columns the 16-byte walk covers -- G, or
+    // G rounded up to 4 when every row involved is at least that long (the sources' pad columns, zeros, are then copied).
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
     if (idx32_out && threadIdx.x == 0) {
@@ -673,20 +675,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         if (r == n - 1)
             for (int64_t q = n; q < n_pad; ++q) idx32_out[q] = (int32_t)src;  // padding: any valid row
     }
-    const float* xs = X + src * G;
-    float* xd = x_out ? x_out + r * G : nullptr;
+    const float* xs = X + src * ldX;
+    float* xd = x_out ? x_out + r * ldxo : nullptr;
     const bool copy_good = goodloc && goodloc_out;
     if (!xd && !xin_out && !xin2_out && !copy_good) {
         // nothing per gene: the consumers read the resident rows themselves
     } else if (vec_ok) {
-        const int64_t gv = G >> 2;
+        const int64_t gv = Gw >> 2;
         auto emit = [&](int64_t c, const f32x4& v, unsigned gm) {
             if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
             if (xin_out || xin2_out) {
                 f32x4 t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = apply_log ? log1p_count(v[e]) : v[e];
-                if (center) t -= reinterpret_cast<const f32x4*>(center)[c];
+                if (center) {
+                    if (c * 4 + 4 <= G) {
+                        t -= reinterpret_cast<const f32x4*>(center)[c];
+                    } else {  // the chunk that holds the pad columns: center has G entries
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c * 4 + e < G) t[e] -= center[c * 4 + e];
+                    }
+                }
                 if (xin_out) {
                     TX* dst = xin_out + r * ldxin + c * 4;
                     if constexpr (sizeof(TX) == 2) {
@@ -721,9 +731,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
                     }
                 }
             }
-            if (copy_good) reinterpret_cast<unsigned int*>(goodloc_out + r * G)[c] = gm;
+            if (copy_good) reinterpret_cast<unsigned int*>(goodloc_out + r * ldgo)[c] = gm;
         };
-        const unsigned int* gs = copy_good ? reinterpret_cast<const unsigned int*>(goodloc + src * G) : nullptr;
+        const unsigned int* gs = copy_good ? reinterpret_cast<const unsigned int*>(goodloc + src * ldg) : nullptr;
         int64_t c = threadIdx.x;
         for (; c + 768 < gv; c += 1024) {  // four independent 16-byte loads in flight per thread
             f32x4 v[4];
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             const float t = (apply_log ? log1p_count(v) : v) - (center ? center[c] : 0.f);
             if (xin_out) st_from_f32<TX>(xin_out + r * ldxin + c, t);
             if (xin2_out) xin2_out[r * ldxin2 + c] = f2bf(t);
-            if (copy_good) goodloc_out[r * G + c] = goodloc[src * G + c];
+            if (copy_good) goodloc_out[r * ldgo + c] = goodloc[src * ldg + c];
         }
     }
     if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
@@ -1329,13 +1339,16 @@ extern "C" int c2_reparam_kl_bwd(const float* dZ, int64_t lddz, int nslab, int64
     return 0;
 }
 
-extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
-                              const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
-                              float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
-                              int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
-                              const float* rowconst, float* rowconst_out, int32_t* idx32_out, int64_t idx32_len,
-                              const float* center, void* xin2_out, int64_t ldxin2, void* stream) {
+extern "C" int c2_gather_rows_ld(const float* X, int64_t ldX, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                                 const int64_t* cond, const int64_t* classes, int64_t G, int C, int P, const int64_t* idx,
+                                 int64_t n, float* x_out, int64_t ldx_out, uint8_t* goodloc_out, int64_t ldg_out,
+                                 float* sf_out, int64_t* cond_out, int64_t* classes_out, void* xin_out, int xin_dtype,
+                                 int64_t ldxin, int apply_log, const float* rowconst, float* rowconst_out,
+                                 int32_t* idx32_out, int64_t idx32_len, const float* center, void* xin2_out,
+                                 int64_t ldxin2, void* stream) {
     C2_CHECK(X && idx, "null pointer");
+    C2_CHECK(ldX >= G && (!goodloc || ldg >= G) && (!x_out || ldx_out >= G) && (!goodloc_out || ldg_out >= G),
+             "a row pitch is shorter than the gene count");
     C2_CHECK(!center || xin_out || xin2_out, "center given without xin_out");
     C2_CHECK(!xin2_out || ldxin2 >= G, "ldxin2 too small");
     C2_CHECK(!xin_out || xin_dtype == C2_F32 || xin_dtype == C2_BF16 || xin_dtype == C2_F16, "bad xin dtype");
@@ -1346,8 +1359,16 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
     C2_CHECK(!classes || classes_out, "classes_out missing");
     C2_CHECK(!xin_out || ldxin >= G, "ldxin too small");
     if (n == 0 || G == 0) return 0;
-    const int vec_ok = (G % 4 == 0) && aligned16(X) && (!x_out || aligned16(x_out)) && (!center || aligned16(center)) &&
-                       (!(goodloc && goodloc_out) || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0));
+    const bool copy_good = goodloc && goodloc_out;
+    // the 16-byte walk: over G when that is a multiple of 4, else over G rounded up when every row involved is that long
+    const int64_t G4 = (G + 3) / 4 * 4;
+    const bool rows_cover = ldX >= G4 && (!x_out || ldx_out >= G4) && (!copy_good || (ldg >= G4 && ldg_out >= G4)) &&
+                            (!xin_out || ldxin >= G4) && (!xin2_out || ldxin2 >= G4);
+    const int64_t Gw = (G % 4 == 0) ? G : (rows_cover ? G4 : 0);
+    const int vec_ok = Gw > 0 && aligned16(X) && ldX % 4 == 0 && (!x_out || (aligned16(x_out) && ldx_out % 4 == 0)) &&
+                       (!center || aligned16(center)) &&
+                       (!copy_good || (((uintptr_t)goodloc & 3) == 0 && ((uintptr_t)goodloc_out & 3) == 0 && ldg % 4 == 0 &&
+                                       ldg_out % 4 == 0));
     const int vec_xin = xin_out && aligned16(xin_out) && (ldxin % 8 == 0);
     const int vec_xin2 = xin2_out && aligned16(xin2_out) && (ldxin2 % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -1355,19 +1376,30 @@ extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const floa
         hipLaunchKernelGGL((gather_rows_kernel<f16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (f16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len,
-                           center, (bf16_t*)xin2_out, ldxin2, vec_xin2);
+                           center, (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);
     else if (xin_out && xin_dtype == C2_BF16)
         hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
-                           (bf16_t*)xin2_out, ldxin2, vec_xin2);
+                           (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
-                           (bf16_t*)xin2_out, ldxin2, vec_xin2);
+                           (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);
     C2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefactor, const int64_t* cond,
+                              const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
+                              float* x_out, uint8_t* goodloc_out, float* sf_out, int64_t* cond_out,
+                              int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
+                              const float* rowconst, float* rowconst_out, int32_t* idx32_out, int64_t idx32_len,
+                              const float* center, void* xin2_out, int64_t ldxin2, void* stream) {
+    return c2_gather_rows_ld(X, G, goodloc, G, sizefactor, cond, classes, G, C, P, idx, n, x_out, G, goodloc_out, G, sf_out,
+                             cond_out, classes_out, xin_out, xin_dtype, ldxin, apply_log, rowconst, rowconst_out, idx32_out,
+                             idx32_len, center, xin2_out, ldxin2, stream);
 }
 
 extern "C" int c2_dropout_masks(uint8_t* out, int64_t n, float p_drop, uint64_t seed, uint64_t offset, void* stream) {

@@ -82,11 +82,14 @@ class DeviceDataset:
         X = np.ascontiguousarray(np.asarray(adata.X), dtype=np.float32)
         self.n, self.G = X.shape
         sf = np.asarray(adata.obs["celligner2_size_factors"], dtype=np.float32).reshape(-1)
-        self.data = torch.from_numpy(X).to(self.device)
+        # counts and mask live in HBM ONCE, rows G rounded up to 4 elements apart (pad columns: count 0, mask 0), so that
+        # every row starts on 16 / 4 bytes whatever the gene count and the likelihood kernels walk it in 16-byte chunks
+        self.data = self._pitched(torch.from_numpy(X), torch.float32)
         self.size_factors = torch.from_numpy(sf).to(self.device)
         if goodloc is None:
-            goodloc = np.ones(X.shape, dtype=bool)
-        self.goodloc = torch.as_tensor(np.ascontiguousarray(goodloc), dtype=torch.bool).to(self.device)
+            self.goodloc = self._pitched(None, torch.bool)
+        else:
+            self.goodloc = self._pitched(torch.as_tensor(np.ascontiguousarray(goodloc), dtype=torch.bool), torch.bool)
         self.conditions = None
         self.predictors = None
         if self.condition_keys is not None:
@@ -101,13 +104,37 @@ class DeviceDataset:
     def __len__(self):
         return self.n
 
+    def _pitched(self, src, dtype, chunk=16384):
+        """[n, G] view over a zero-initialised [n, G rounded up to 4] device matrix holding `src` (host or device tensor; None:
+        all ones), filled in row chunks (no second full-size temporary)."""
+        g4 = (self.G + 3) // 4 * 4
+        if src is not None and g4 == self.G:
+            return src.to(self.device, dtype).contiguous()
+        full = torch.zeros((self.n, g4), dtype=dtype, device=self.device)
+        view = full[:, :self.G]
+        for s0 in range(0, self.n, chunk):
+            if src is None:
+                view[s0:s0 + chunk] = True
+            else:
+                view[s0:s0 + chunk] = src[s0:s0 + chunk].to(self.device, dtype)
+        return view
+
     @classmethod
-    def from_tensors(cls, data, size_factors, goodloc, conditions=None, predictors=None, minweight=0.0):
-        """Wrap tensors that already live on the GPU (synthetic benchmarks, pre-staged matrices)."""
+    def from_tensors(cls, data, size_factors, goodloc, conditions=None, predictors=None, minweight=0.0, repitch=False):
+        """Wrap tensors that already live on the GPU (synthetic benchmarks, pre-staged matrices).  [n, G] views whose rows
+        are G rounded up to 4 elements apart with zero pad columns (count 0, mask 0) are used as they are.  repitch=True:
+        at a gene count that is not a multiple of 4, contiguous `data` / `goodloc` are copied ONCE into such matrices and
+        the dataset keeps only the copies (the caller may free its own); otherwise the fast likelihood path makes its
+        padded copies on first use and the dataset holds both (resident_rows4)."""
         self = cls.__new__(cls)
         self.minweight = minweight
         self.device = data.device
         self.n, self.G = data.shape
+        if repitch and self.G % 4:
+            if data.stride(0) % 4:
+                data = self._pitched(data, data.dtype)
+            if goodloc.stride(0) % 4:
+                goodloc = self._pitched(goodloc, goodloc.dtype)
         self.data, self.size_factors, self.goodloc = data, size_factors, goodloc
         self.conditions, self.predictors = conditions, predictors
         self.condition_keys = ["condition"] if conditions is not None else None
@@ -148,11 +175,13 @@ class DeviceDataset:
         return c
 
     def resident_rows4(self):
-        """(counts, mask) as [n, G] views whose rows start on 16 / 4 bytes: the matrices themselves when G is a multiple
-        of 4, else copies with zero pad columns up to the next multiple (made once; the NB loss kernel's fast path walks
-        the rows it is pointed at in 16-byte chunks and takes a masked pad gene for what it is: absent).  The copies
-        double the dataset's footprint for the three gene counts in four that need them."""
-        if self.G % 4 == 0:
+        """(counts, mask) as [n, G] views whose rows are G rounded up to 4 elements apart, pad columns zero: the dataset's own
+        matrices (built that way by the constructor and by from_tensors(repitch=True); any matrix when G is a multiple of
+        4) -- the NB loss kernel's fast path walks the rows it is pointed at in 16-byte chunks and takes a masked pad gene
+        for what it is: absent.  Only a dataset wrapped around contiguous tensors at a gene count that is not a multiple of
+        4 (from_tensors without repitch) makes padded copies here, once, and then holds counts and mask twice."""
+        g4 = (self.G + 3) // 4 * 4
+        if self.data.stride(0) == g4 and self.goodloc.stride(0) == g4:  # (a multiple of 4, or rows padded at construction)
             return self.data, self.goodloc
         c = self.__dict__.get("_rows4")
         if c is None:
@@ -225,12 +254,22 @@ class DeviceDataset:
                 bufs[key] = t
             return t
 
+        def rows4(key, dtype):
+            g4 = (self.G + 3) // 4 * 4
+            if g4 == self.G:
+                return get(key, (n, self.G), dtype)
+            full = bufs.get(key + ".rows4")
+            if full is None or tuple(full.shape) != (n, g4) or full.dtype != dtype:
+                full = bufs[key + ".rows4"] = torch.zeros((n, g4), dtype=dtype, device=self.device)
+            return full[:, :self.G]
+
         out = dict(sizefactor=get("sizefactor", (n,), torch.float32))
         if resident_rows:
             xf, gf = self.resident_rows4()
             out.update(x_full=xf, goodloc_full=gf, row_index=idx.contiguous())
         else:
-            out.update(x=get("x", (n, self.G), torch.float32), goodloc=get("goodloc", (n, self.G), torch.bool))
+            # (gathered copies keep the padded row pitch: the batch takes the same kernels as the resident rows)
+            out.update(x=rows4("x", torch.float32), goodloc=rows4("goodloc", torch.bool))
         cond_o = cls_o = None
         if self.condition_keys:
             cond_o = out["batch"] = get("batch", (n, self.conditions.shape[1]), torch.int64)

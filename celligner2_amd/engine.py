@@ -138,6 +138,7 @@ class StepEngine:
         log_in = bool(cfg["applylog"]) and cfg["recon_loss"] != "mse"
         self.fwd16 = torch.float16 if (self.enc[0].gt == torch.bfloat16 and log_in and not off("C2_FWD16")) else None
         self.half_logits_on = not off("C2_HALF_LOGITS")
+        self.rows4_on = not off("C2_ROWS4")  # padded-row route of the NB / ZINB likelihood at gene counts that are not multiples of 4
         # The backward pass is two chains: activation gradients (tail, input-gradient GEMM, the next layer's tail ...: each
         # waits for the one before) and parameter gradients (bias / condition column sums, weight-gradient GEMM, slab sums:
         # nothing but the optimizer waits for them).  The second chain is queued on a stream of its own (one process, no
@@ -936,9 +937,22 @@ class StepEngine:
         # up, on operands that all have rows of that width -- the dataset's padded copies (DeviceDataset.resident_rows4:
         # mask 0 in the pad), logits with -inf in the pad (a softmax weight of exactly 0), dispersion rows of zeros -- so
         # that its 16-byte row walk applies (910 -> ~220 us at 4096 x 19 001); the pad genes are masked genes.
+        # Batches handed in as tensors take the same route: gathered copies that kept the dataset's row pitch as they are,
+        # contiguous ones through padded copies made here (two strided copies, a fifth of what the general kernel costs more).
         G4 = (G + 3) // 4 * 4
-        wide4 = (G4 != G and cfg["recon_loss"] in ("nb", "zinb") and x is None and batch["x_full"].stride(0) == G4
-                 and batch["goodloc_full"].stride(0) == G4)
+        wide4 = False
+        x_nb = gl_nb = None
+        if G4 != G and cfg["recon_loss"] in ("nb", "zinb") and self.rows4_on:
+            if x is None:
+                wide4 = batch["x_full"].stride(0) == G4 and batch["goodloc_full"].stride(0) == G4
+            else:
+                x_nb, gl_nb = x, batch["goodloc"]
+                if not (x_nb.stride() == (G4, 1) and gl_nb.stride() == (G4, 1)):
+                    x_nb = self.buf("x.rows4", (B, G4), F32, zero=True)[:, :G]
+                    x_nb.copy_(x)
+                    gl_nb = self.buf("goodloc.rows4", (B, G4), batch["goodloc"].dtype, zero=True)[:, :G]
+                    gl_nb.copy_(batch["goodloc"])
+                wide4 = True
         # bf16 mode, NB likelihood at the widths its register-resident kernel takes: the logits leave the output layer's GEMM
         # as IEEE halves (2^-12 of a logit; the same mode rounds the layer's operands and dlogits to 2^-9) -- half the
         # bytes of the step's largest store, and of the loss kernel's largest read
@@ -968,7 +982,7 @@ class StepEngine:
             if x is None:
                 xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
             else:
-                xs, gl, ridx = x, batch["goodloc"], None
+                xs, gl, ridx = (x_nb, gl_nb, None) if wide4 else (x, batch["goodloc"], None)
             # the loss kernel also sums dlogits over the batch (the output layer's bias gradient) while it has them
             theta = self.p["theta"].detach()
             if wide4:
@@ -1007,7 +1021,7 @@ class StepEngine:
             if x is None:
                 xs, gl, ridx = batch["x_full"], batch["goodloc_full"], batch["row_index"]
             else:
-                xs, gl, ridx = x, batch["goodloc"], None
+                xs, gl, ridx = (x_nb, gl_nb, None) if wide4 else (x, batch["goodloc"], None)
             theta = self.p["theta"].detach()
             if wide4:
                 widen = lambda t: t.as_strided((t.shape[0], G4), (t.stride(0), 1), t.storage_offset())  # noqa: E731

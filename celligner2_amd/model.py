@@ -495,12 +495,17 @@ class Celligner2(nn.Module):
         else:
             dev = x.device
             B = x.shape[0]
-            x = x.float().contiguous()
-            if goodloc is None:
-                goodloc = torch.ones_like(x, dtype=torch.bool)
+            # (a batch gathered from a DeviceDataset at a gene count that is not a multiple of 4 keeps its rows G rounded up to
+            # 4 elements apart, pad columns zero / masked: the likelihood kernels read them where they are)
+            G4 = (x.shape[1] + 3) // 4 * 4
+            pitched = (G4 != x.shape[1] and xin is not None and self.recon_loss in ("nb", "zinb") and goodloc is not None
+                       and x.dtype == torch.float32 and x.stride() == (G4, 1) and goodloc.stride() == (G4, 1))
+            if not pitched:
+                x = x.float().contiguous()
+                goodloc = goodloc.contiguous() if goodloc is not None else torch.ones_like(x, dtype=torch.bool)
             if sizefactor is None:
                 sizefactor = x.sum(1)
-            bt = dict(x=x, goodloc=goodloc.contiguous(), sizefactor=sizefactor.reshape(B).float().contiguous())
+            bt = dict(x=x, goodloc=goodloc, sizefactor=sizefactor.reshape(B).float().contiguous())
         if batch is not None:
             bt["batch"] = batch.long().contiguous()
         elif self.n_conditions:

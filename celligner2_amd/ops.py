@@ -729,13 +729,20 @@ def gather_rows(X, goodloc, sizefactor, cond, classes, idx, x_out, goodloc_out, 
     n = idx.numel()
     C = cond.shape[1] if cond is not None else 0
     P = classes.shape[1] if classes is not None else 0
-    assert X.is_contiguous() and (x_out is None or x_out.is_contiguous()) and idx.dtype == torch.int64
-    check(lib.c2_gather_rows(ptr(X), ptr(goodloc), ptr(sizefactor), ptr(cond), ptr(classes), G, C, P, ptr(idx), n,
-                             ptr(x_out), ptr(goodloc_out), ptr(sf_out), ptr(cond_out), ptr(classes_out), ptr(xin_out),
-                             dt_code(xin_out.dtype) if xin_out is not None else 0,
-                             xin_out.stride(0) if xin_out is not None else 0, int(apply_log), ptr(rowconst),
-                             ptr(rowconst_out), ptr(idx32_out), idx32_out.numel() if idx32_out is not None else 0,
-                             ptr(center), ptr(xin2_out), xin2_out.stride(0) if xin2_out is not None else 0, stream()))
+    assert idx.dtype == torch.int64
+
+    def pitch(t, what):  # rows `pitch` elements apart, unit stride inside a row (a dataset with padded rows: c2_gather_rows_ld)
+        if t is None:
+            return 0
+        assert t.dim() == 2 and t.shape[1] == G and (t.stride(1) == 1 or t.shape[1] <= 1) and t.stride(0) >= G, what
+        return t.stride(0)
+    check(lib.c2_gather_rows_ld(ptr(X), pitch(X, "X"), ptr(goodloc), pitch(goodloc, "goodloc"), ptr(sizefactor), ptr(cond),
+                                ptr(classes), G, C, P, ptr(idx), n, ptr(x_out), pitch(x_out, "x_out"), ptr(goodloc_out),
+                                pitch(goodloc_out, "goodloc_out"), ptr(sf_out), ptr(cond_out), ptr(classes_out),
+                                ptr(xin_out), dt_code(xin_out.dtype) if xin_out is not None else 0,
+                                xin_out.stride(0) if xin_out is not None else 0, int(apply_log), ptr(rowconst),
+                                ptr(rowconst_out), ptr(idx32_out), idx32_out.numel() if idx32_out is not None else 0,
+                                ptr(center), ptr(xin2_out), xin2_out.stride(0) if xin2_out is not None else 0, stream()))
 
 
 def defer_loss_sums(on):

@@ -367,6 +367,17 @@ int c2_gather_rows(const float* X, const uint8_t* goodloc, const float* sizefact
                    int xin_dtype, int64_t ldxin, int apply_log, const float* rowconst, float* rowconst_out,
                    int32_t* idx32_out, int64_t idx32_len, const float* center, void* xin2_out, int64_t ldxin2,
                    void* stream);
+/* c2_gather_rows with row pitches (elements) for the resident matrices and the gathered copies: X [rows, ldX], goodloc
+ * [rows, ldg], x_out [n, ldx_out], goodloc_out [n, ldg_out].  A dataset whose gene count is not a multiple of 4 keeps its rows
+ * G4 = G rounded up to 4 elements apart, pad columns zero (counts 0, mask 0): rows then start on 16 / 4 bytes and the
+ * likelihood kernels walk them in 16-byte chunks.  When every row involved is at least G4 long the gather walks G4 columns
+ * too and copies the sources' pad columns with the rest (so zero pads stay zero pads); center keeps G entries. */
+int c2_gather_rows_ld(const float* X, int64_t ldX, const uint8_t* goodloc, int64_t ldg, const float* sizefactor,
+                      const int64_t* cond, const int64_t* classes, int64_t G, int C, int P, const int64_t* idx, int64_t n,
+                      float* x_out, int64_t ldx_out, uint8_t* goodloc_out, int64_t ldg_out, float* sf_out,
+                      int64_t* cond_out, int64_t* classes_out, void* xin_out, int xin_dtype, int64_t ldxin, int apply_log,
+                      const float* rowconst, float* rowconst_out, int32_t* idx32_out, int64_t idx32_len,
+                      const float* center, void* xin2_out, int64_t ldxin2, void* stream);
 
 /* ---- BatchNorm1d form of the layer tail (use_bn=True: modules.py:298-302, 405-413, 445-449, 557-566, 596-600;
  * nn.BatchNorm1d(affine=True), eps 1e-5, momentum 0.1).  The statistics run over the batch, so the tail is cut at

@@ -82,43 +82,78 @@ def test_two_part_weight_gradient_with_a_strip_below_the_256_kernel():
 @pytest.mark.parametrize("recon", ["nb", "zinb"])
 @pytest.mark.parametrize("precision,G", [("fp32", 2051), ("bf16", 2051), ("bf16", 2050), ("fp32", 701)])
 def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precision, G, recon):
-    """The NB likelihood on the dataset's resident rows runs over the gene count rounded up to 4 (padded copies of the
-    counts and the mask, -inf logits and zero dispersion rows in the pad: engine._forward, DeviceDataset.resident_rows4) so
-    that the loss kernel's 16-byte row walk applies.  Pinned against the same step on gathered copies of the rows, which
-    takes the general kernel on the unpadded operands: losses and every gradient (two kernels, two summation orders)."""
+    """The NB likelihood at a gene count that is not a multiple of 4 runs over the count rounded up to 4, on rows that are
+    that far apart with zero / masked pad columns (-inf logits and zero dispersion rows in the pad: engine._forward), so that
+    the loss kernel's 16-byte row walk applies.  The dataset keeps its counts and mask in that form ONCE (constructor,
+    from_tensors(repitch=True): no second copy), gathered batches keep the pitch, contiguous tensor batches are padded
+    on the way in.  All three are pinned against the same step on the general kernel (C2_ROWS4=0 / engine.rows4_on) on
+    unpadded operands: losses and every gradient (two kernels, two summation orders) -- and the evaluation forward too."""
     import torch
     from celligner2_amd.dataset import DeviceDataset
     from celligner2_amd.model import Celligner2
     N, B, L, C = 600, 256, 12, 3
+    G4 = (G + 3) // 4 * 4
     g = torch.Generator(device="cuda")
     g.manual_seed(G)
     X = torch.poisson(torch.exp(torch.randn(1, G, device="cuda", generator=g) + 0.5).expand(N, G).contiguous(), generator=g)
     good = torch.rand(N, G, device="cuda", generator=g) > 0.01
     cond = torch.zeros(N, C, dtype=torch.int64, device="cuda")
     cond[torch.arange(N, device="cuda"), torch.randint(0, C, (N,), device="cuda", generator=g)] = 1
-    data = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None)
+    data = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None, repitch=True)
+    assert data.data.stride(0) == G4 and data.goodloc.stride(0) == G4 and torch.equal(data.data, X)
+    assert data.data.untyped_storage().nbytes() == N * G4 * 4  # the padded matrix and nothing else
+    plain = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None)  # contiguous rows: the legacy form
     idx = torch.randperm(N, device="cuda", generator=g)[:B]
     eps = torch.randn(B, L, device="cuda", generator=g)
     torch.manual_seed(1)
     m = Celligner2(G, [96, 40], L, 0.0, False, recon, conditions=["a", "b", "c"], use_mmd=True, beta=5.0,
                    precision=precision).cuda().train()
-    xt = m._engine().enc[0].gt
-    out = {}
-    for resident in (True, False):
-        batch = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=resident, **m._engine().input_spec()))
-        assert ("x_full" in batch) == resident
-        if resident:
-            assert batch["x_full"].stride(0) == (G + 3) // 4 * 4 and batch["goodloc_full"].stride(0) == (G + 3) // 4 * 4
+    eng = m._engine()
+    spec = eng.input_spec()
+
+    def step(batch, rows4=True, train=True):
+        eng.rows4_on = rows4
+        m.train(train)
         m._forced_noise = dict(eps=eps, masks={})
         for p in m.parameters():
             p.grad = None
-        total, v = m.forward_total((1.0, 1e-3, 1.0, 1.0), **batch)
-        total.backward(gradient=torch.ones((), device="cuda"))
-        m._engine().check_status()
-        out[resident] = (v.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-    (v1, g1), (v0, g0) = out[True], out[False]
-    assert torch.isfinite(v1).all() and torch.allclose(v1, v0, rtol=2e-5, atol=1e-6), (v1, v0)
+        try:
+            if not train:
+                with torch.no_grad():
+                    return torch.stack(m(**batch)).clone(), None
+            total, v = m.forward_total((1.0, 1e-3, 1.0, 1.0), **batch)
+            total.backward(gradient=torch.ones((), device="cuda"))
+            eng.check_status()
+            return v.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            eng.rows4_on = True
+            m.train(True)
+
+    res = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **spec))
+    assert res["x_full"] is data.data and res["goodloc_full"] is data.goodloc and "_rows4" not in data.__dict__
+    gat = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=False, **spec))
+    assert gat["x"].stride(0) == G4 and gat["goodloc"].stride(0) == G4 and torch.equal(gat["x"], X[idx])
+    assert torch.equal(gat["goodloc"], good[idx])
+    full = gat["x"].as_strided((B, G4), (G4, 1), gat["x"].storage_offset())
+    assert float(full[:, G:].abs().max()) == 0.0  # the pad travelled with the rows
+    ten = dict(plain.gather(idx, apply_log=True, nb_const=True, resident_rows=False, **spec))
+    ten["x"], ten["goodloc"] = ten["x"].contiguous(), ten["goodloc"].contiguous()
+    assert ten["x"].stride(0) == G
+    v0, g0 = step(ten, rows4=False)  # the general kernel on unpadded operands
     tol = 2e-4 if precision == "fp32" else 2e-2  # (bf16 mode: the two kernels round dlogits from sums in two orders)
-    for n in g0:
-        e = float((g1[n].double() - g0[n].double()).norm() / g0[n].double().norm().clamp_min(1e-30))
-        assert e < tol, (n, e)
+    for name, batch in (("resident", res), ("gathered", gat), ("tensors", ten)):
+        v1, g1 = step(batch)
+        assert torch.isfinite(v1).all() and torch.allclose(v1, v0, rtol=2e-5, atol=1e-6), (name, v1, v0)
+        for n in g0:
+            e = float((g1[n].double() - g0[n].double()).norm() / g0[n].double().norm().clamp_min(1e-30))
+            assert e < tol, (name, n, e)
+    # the evaluation forward (validation, trainer.py:330-352) takes the same route
+    e0, _ = step(ten, rows4=False, train=False)
+    for name, batch in (("resident", res), ("gathered", gat), ("tensors", ten)):
+        e1, _ = step(batch, train=False)
+        assert torch.isfinite(e1).all() and torch.allclose(e1, e0, rtol=2e-5, atol=1e-6), (name, e1, e0)
+    # the legacy form still works: padded copies made on first use, the dataset then holds both
+    leg = dict(plain.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **spec))
+    assert leg["x_full"].stride(0) == G4 and "_rows4" in plain.__dict__
+    v2, _ = step(leg)
+    assert torch.allclose(v2, v0, rtol=2e-5, atol=1e-6)
