@@ -433,15 +433,18 @@ __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, bool two, float& v0
 // DIRECT (short batches, B <= kBCG_DIRECT_B): one launch -- a block walks ALL rows of its 128 columns and writes alpha * sum
 // straight to db / dWc; at the reference's default batch of 128 the second stage was a launch with nothing to combine.
 constexpr int kBCG_DIRECT_B = 256;
-template <typename TI, int CC, bool DIRECT = false>
+// CXN: column pairs per block (64: 128 columns x 8 row groups; 16: 32 columns x 32 row groups -- the DIRECT form, whose few
+// blocks each walk every row: at 128 rows x 256 columns two blocks took 13.7 us, a chain of 16 dependent row steps).
+template <typename TI, int CC, bool DIRECT = false, int CXN = 64>
 __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ dh, int64_t lddh,
                                                         const int64_t* __restrict__ cond, int C, int c0, int64_t B, int H,
                                                         float* __restrict__ ws /*[nchunk][1+C][H]*/,
                                                         float* __restrict__ db = nullptr, float* __restrict__ dWc = nullptr,
                                                         int64_t lddwc = 0, const float* __restrict__ alpha_dev = nullptr) {
-    __shared__ float red[8][(1 + CC)][128];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.x * 128 + 2 * cx;
+    constexpr int RYN = 512 / CXN, NCOL = 2 * CXN;
+    __shared__ float red[RYN][(1 + CC)][NCOL];
+    const int cx = threadIdx.x % CXN, ry = threadIdx.x / CXN;
+    const int col = blockIdx.x * NCOL + 2 * cx;
     const int chunk = blockIdx.y;
     const int64_t b0 = DIRECT ? 0 : (int64_t)chunk * kBCG_RB, b1 = DIRECT ? B : min(B, b0 + kBCG_RB);
     float a0[2] = {0.f, 0.f};
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
     for (int j = 0; j < CC; ++j) acc[j][0] = acc[j][1] = 0.f;
     if (col < H) {
         const bool two = col + 1 < H;
-        for (int64_t b = b0 + ry; b < b1; b += 8) {
+        for (int64_t b = b0 + ry; b < b1; b += RYN) {
             float v0, v1;
             ld2<TI>(dh + b * lddh + col, two, v0, v1);
             a0[0] += v0;
@@ -472,15 +475,15 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
     }
     __syncthreads();
     float* out = ws + (int64_t)chunk * (1 + C) * H;
-    for (int i = threadIdx.x; i < (1 + CC) * 128; i += 512) {
-        const int k = i >> 7, c = i & 127;
-        const int gc = blockIdx.x * 128 + c;
+    for (int i = threadIdx.x; i < (1 + CC) * NCOL; i += 512) {
+        const int k = i / NCOL, c = i % NCOL;
+        const int gc = blockIdx.x * NCOL + c;
         if (gc >= H) continue;
         if (k == 0 && c0 != 0) continue;          // the bias row is written by the first condition group only
         if (k > 0 && c0 + k - 1 >= C) continue;
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += red[r][k][c];
+        for (int r = 0; r < RYN; ++r) s += red[r][k][c];
         if (DIRECT) {
             s *= alpha_dev ? *alpha_dev : 1.f;
             if (k == 0) {
@@ -668,9 +671,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     int vec_xin2, int64_t ldX, int64_t ldg, int64_t ldxo, int64_t ldgo, int64_t Gw) {
     // ldX / ldg / ldxo / ldgo: row pitches of X, goodloc, x_out, goodloc_out.  Gw: the columns the 16-byte walk covers -- G, or
     // G rounded up to 4 when every row involved is at least that long (the sources' pad columns, zeros, are then copied).
+    // blockIdx.y: the part of the row's columns this block moves (short batches: one block per row would leave most of the
+    // chip idle); the per-row scalars travel with part 0
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
-    if (idx32_out && threadIdx.x == 0) {
+    const int part = blockIdx.y, nparts = gridDim.y;
+    if (idx32_out && threadIdx.x == 0 && part == 0) {
         idx32_out[r] = (int32_t)src;
         if (r == n - 1)
             for (int64_t q = n; q < n_pad; ++q) idx32_out[q] = (int32_t)src;  // padding: any valid row
@@ -734,8 +740,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             if (copy_good) reinterpret_cast<unsigned int*>(goodloc_out + r * ldgo)[c] = gm;
         };
         const unsigned int* gs = copy_good ? reinterpret_cast<const unsigned int*>(goodloc + src * ldg) : nullptr;
-        int64_t c = threadIdx.x;
-        for (; c + 768 < gv; c += 1024) {  // four independent 16-byte loads in flight per thread
+        const int64_t per = ((gv + nparts - 1) / nparts + 255) / 256 * 256;  // chunks per part, whole thread rounds
+        const int64_t gv0 = gv;
+        const int64_t cbeg = min(gv0, (int64_t)part * per), cend = min(gv0, cbeg + per);
+        int64_t c = cbeg + threadIdx.x;
+        for (; c + 768 < cend; c += 1024) {  // four independent 16-byte loads in flight per thread
             f32x4 v[4];
             unsigned gm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -747,9 +756,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) emit(c + 256 * u, v[u], gm[u]);
         }
-        for (; c < gv; c += 256) emit(c, reinterpret_cast<const f32x4*>(xs)[c], copy_good ? gs[c] : 0u);
+        for (; c < cend; c += 256) emit(c, reinterpret_cast<const f32x4*>(xs)[c], copy_good ? gs[c] : 0u);
     } else {
-        for (int64_t c = threadIdx.x; c < G; c += 256) {
+        const int64_t per = ((G + nparts - 1) / nparts + 255) / 256 * 256;
+        const int64_t cbeg = min(G, (int64_t)part * per), cend = min(G, cbeg + per);
+        for (int64_t c = cbeg + threadIdx.x; c < cend; c += 256) {
             const float v = xs[c];
             if (xd) xd[c] = v;
             const float t = (apply_log ? log1p_count(v) : v) - (center ? center[c] : 0.f);
@@ -758,6 +769,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
             if (copy_good) goodloc_out[r * ldgo + c] = goodloc[src * ldg + c];
         }
     }
+    if (part != 0) return;
     if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
     if (threadIdx.x == 0 && rowconst) rowconst_out[r] = rowconst[src];
     if (cond)
@@ -1234,9 +1246,9 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
     if (!dWc) C = 0;
     hipStream_t st = (hipStream_t)stream;
     if (B <= kBCG_DIRECT_B) {  // one launch, no second stage
-        dim3 g1((unsigned)((H + 127) / 128));
+        dim3 g1((unsigned)((H + 31) / 32));
 #define BCD_L(TI, CC, c0)                                                                                              \
-    hipLaunchKernelGGL((bias_cond_stage1<TI, CC, true>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, \
+    hipLaunchKernelGGL((bias_cond_stage1<TI, CC, true, 16>), g1, dim3(512), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, \
                        ws, db, dWc, lddwc, alpha_dev)
         for (int c0 = 0; c0 == 0 || c0 < C; c0 += kBCG_MAXC) {
             const int left = C - c0;
@@ -1372,18 +1384,23 @@ extern "C" int c2_gather_rows_ld(const float* X, int64_t ldX, const uint8_t* goo
     const int vec_xin = xin_out && aligned16(xin_out) && (ldxin % 8 == 0);
     const int vec_xin2 = xin2_out && aligned16(xin2_out) && (ldxin2 % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
+    // short batches with per-gene work: several blocks per row, so that the launch is ~1024 blocks (each at least 1024 genes)
+    const bool per_gene = x_out || xin_out || xin2_out || copy_good;
+    unsigned parts = 1;
+    if (per_gene && n < 1024) parts = (unsigned)std::max<int64_t>(1, std::min<int64_t>((1024 + n - 1) / n, G / 1024));
+    const dim3 grid((unsigned)n, parts);
     if (xin_out && xin_dtype == C2_F16)
-        hipLaunchKernelGGL((gather_rows_kernel<f16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+        hipLaunchKernelGGL((gather_rows_kernel<f16_t>), grid, dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (f16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len,
                            center, (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);
     else if (xin_out && xin_dtype == C2_BF16)
-        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+        hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), grid, dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (bf16_t*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
                            (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);
     else
-        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)n), dim3(256), 0, st, X, goodloc, sizefactor,
+        hipLaunchKernelGGL((gather_rows_kernel<float>), grid, dim3(256), 0, st, X, goodloc, sizefactor,
                            cond, classes, G, C, P, idx, x_out, goodloc_out, sf_out, cond_out, classes_out,
                            (float*)xin_out, ldxin, apply_log, vec_ok, vec_xin, rowconst, rowconst_out, idx32_out, n, idx32_len, center,
                            (bf16_t*)xin2_out, ldxin2, vec_xin2, ldX, ldg, ldx_out, ldg_out, Gw);

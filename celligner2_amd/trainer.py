@@ -268,6 +268,13 @@ class _StepGraph:
             # (data-parallel: the process group's watchdog thread makes HIP calls of its own while this thread captures --
             # only this thread's calls belong to the capture)
             mode = {"capture_error_mode": "thread_local"} if t.world is not None else {}
+            if t.world is not None:
+                # ... and it must find nothing to do meanwhile: the collectives of the warm-up steps are complete (the
+                # synchronize above) but stay on the watchdog's list until its next pass (every 100 ms), and a pass that
+                # retires them while this thread captures queries and destroys their events inside the capture window --
+                # seen once in ~25 captures as an exception in the watchdog thread, which ends the process (SIGABRT).
+                # Two and a half of its periods, once per training run.
+                time.sleep(0.25)
             steps = t.optimizer.step_counts()
             try:
                 with torch.cuda.graph(graph, **mode):

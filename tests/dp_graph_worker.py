@@ -39,6 +39,8 @@ def run(variant, graph):
 
 
 def main():
+    from tests.ddp_worker import _own_stderr
+    _own_stderr()  # (this rank's error stream in a file of its own: an abort's message survives torchrun's tail)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     variant = sys.argv[1]
@@ -61,7 +63,7 @@ def main():
     if s0 != s1:
         ok = False
         print("MISMATCH optimizer step counts", s0[:3], s1[:3])
-    print("dp graph worker", variant, "ok" if ok else "FAILED", "replays", t1.graph_replays)
+    print("dp graph worker", variant, "ok" if ok else "FAILED", "replays", t1.graph_replays, flush=True)
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

@@ -17,7 +17,7 @@ def _run(cmd, env, tag):
         per_rank = ""
         for f in sorted(os.listdir(logs)) if os.path.isdir(logs) else []:
             per_rank += f"\n--- {f}\n" + open(os.path.join(logs, f)).read()[-3000:]
-        raise AssertionError(r.stdout[-3000:] + r.stderr[-3000:] + per_rank)
+        raise AssertionError(r.stdout[-3000:] + r.stderr[:1500] + "\n...\n" + r.stderr[-3000:] + per_rank)
 
 
 @pytest.mark.parametrize("variant", ["ln", "bn", "noise", "shard", "shard_bf16"])
