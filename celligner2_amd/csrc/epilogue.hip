@@ -889,6 +889,20 @@ __global__ __launch_bounds__(256) void finalize_combine_kernel(PendingSums p, fl
 __global__ void scale4_dev_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out) {
     if (threadIdx.x < 4) out[threadIdx.x] = w[threadIdx.x] * (g ? g[0] : 1.f);
 }
+// The backward seed and the two vectors it scales first, in one launch: out4 = w * g (as scale4_dev_kernel), y1 = out4[0] * x1,
+// y2 = out4[0] * x2 -- the output layer's bias gradient and the dispersion gradient, which the NB loss kernel left as
+// unit-upstream sums.  Every block forms out4[0] from w and g itself; block 0 writes out4.
+__global__ void scale4_dev_scale2_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out,
+                                         const float* __restrict__ x1, float* __restrict__ y1, int64_t n1,
+                                         const float* __restrict__ x2, float* __restrict__ y2, int64_t n2) {
+    const float up = g ? g[0] : 1.f;
+    const float s = w[0] * up;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * 256) {
+        if (i < n1) y1[i] = s * x1[i];
+        else y2[i - n1] = s * x2[i - n1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 4) out[threadIdx.x] = w[threadIdx.x] * up;
+}
 // Dropout masks with the Philox counter offset in device memory; a second one-thread launch advances it after every
 // block of the mask kernel has read it (stream order).
 __global__ void dropout_mask_dev_kernel(uint8_t* __restrict__ out, int64_t n, unsigned thresh8, unsigned long long seed,
@@ -1490,6 +1504,15 @@ extern "C" int c2_combine_losses_dev(const float* losses4, const float* w_dev, f
 extern "C" int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* stream) {
     C2_CHECK(w_dev && out4, "null pointer");
     hipLaunchKernelGGL(scale4_dev_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_dev, w_dev, out4);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_scale4_dev_scale2(const float* g_dev, const float* w_dev, float* out4, const float* x1, float* y1,
+                                    int64_t n1, const float* x2, float* y2, int64_t n2, void* stream) {
+    C2_CHECK(w_dev && out4 && n1 >= 0 && n2 >= 0 && (n1 == 0 || (x1 && y1)) && (n2 == 0 || (x2 && y2)), "null pointer");
+    hipLaunchKernelGGL(scale4_dev_scale2_kernel, dim3(grid_for(std::max<int64_t>(n1 + n2, 1))), dim3(256), 0,
+                       (hipStream_t)stream, g_dev, w_dev, out4, x1, y1, n1, x2, y2, n2);
     C2_LAUNCH_CHECK();
     return 0;
 }

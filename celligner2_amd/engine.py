@@ -1076,10 +1076,12 @@ class StepEngine:
         return losses
 
     # ------------------------------------------------------------------ backward
-    def backward(self, g, gen=None):
+    def backward(self, g, gen=None, seed=None):
         """g: fp32 device tensor [4] = upstream gradients of (recon, kl, mmd, class_ce).
         Fills self.grad[name] for every parameter with requires_grad and returns that dict.
-        gen: the generation number of the forward this backward belongs to (checked when given)."""
+        gen: the generation number of the forward this backward belongs to (checked when given).
+        seed = (upstream gradient of the weighted total or None, fp32 [4] device weights): g is still to be formed as
+        weights * upstream -- done by the pass's first launch together with the two vectors that g[0] scales first."""
         if gen is not None and gen != getattr(self, "generation", None):
             raise RuntimeError(
                 "backward of a forward whose saved activations have been overwritten: the engine keeps ONE workspace per "
@@ -1091,6 +1093,7 @@ class StepEngine:
         B, cond, masks = self._B, self._cond, self._masks
         self._touched = set()  # parameters outside this step's graph get no gradient (torch leaves .grad None)
         self._slab_jobs = []
+        self._seed = seed
         try:
             return self._backward(g, cfg, B, cond, masks)
         finally:
@@ -1104,6 +1107,18 @@ class StepEngine:
         G = dlogits.shape[1]
         # ---- decoder output layer
         hw, hb = self.head + ".weight", self.head + ".bias"
+        # what the loss kernel left as unit-upstream sums (the output layer's bias gradient, the dispersion gradient) times gr
+        unit_jobs = []
+        if rq(hb) and self._ws.get("dbias.unit") is not None:
+            unit_jobs.append((self._ws["dbias.unit"], self.gbuf(hb)))
+        if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
+            unit_jobs.append((self._ws["dtheta.unit"], self.gbuf("theta")))
+        if self._seed is not None:
+            ops.scale4_dev_scale2(self._seed[0], self._seed[1], g, unit_jobs)
+            self._seed = None
+        else:
+            for src, dst in unit_jobs:
+                ops.scale(src, gr, dst)
         H1 = self.p[hw].shape[1]
         ns1 = self._dgrad_nslab(dlogits, hw)
         ns2 = self._dgrad_nslab(dlogits, self.head2 + ".weight") if self.head2 else 0
@@ -1116,20 +1131,15 @@ class StepEngine:
         with self._param_side(1):
             if rq(hw):
                 self._wgrad(dlogits, self._dlast, hw, alpha=gr)
-            if rq(hb):
-                if self._ws.get("dbias.unit") is not None:  # (NB: formed by the loss kernel)
-                    ops.scale(self._ws["dbias.unit"], gr, self.gbuf(hb))
-                else:
-                    ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
-                    ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
+            if rq(hb) and self._ws.get("dbias.unit") is None:  # (NB: formed by the loss kernel, scaled above)
+                ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
+                ops.bias_cond_grad(dlogits, None, self.gbuf(hb), None, ws, alpha=gr)
             if self.head2:
                 if rq(h2w):
                     self._wgrad(dpi, self._dlast, h2w, alpha=gr)
                 if rq(h2b):
                     ws = self.buf("bcg.ws.G", (ops.bias_cond_grad_ws(B, G, 0),))
                     ops.bias_cond_grad(dpi, None, self.gbuf(h2b), None, ws, alpha=gr)
-            if cfg["recon_loss"] in ("nb", "zinb") and rq("theta"):
-                ops.scale(self._ws["dtheta.unit"], gr, self.gbuf("theta"))
         self._build_arena()
         self._reduce_bucket(0)  # overlaps everything below
         # ---- decoder hidden blocks, then the first block (mmd_on='y' enters at its output)

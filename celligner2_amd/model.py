@@ -216,10 +216,11 @@ class _StepTotalFn(torch.autograd.Function):
         model = ctx.model
         eng = model.__dict__["_eng"]
         up = gtotal.float().contiguous() if gtotal is not None else None
-        scale4 = ops.scale4_dev if torch.is_tensor(ctx.weights) else ops.scale4
-        g = scale4(up, ctx.weights, eng.buf("gseed", (4,)))
         _keep_accumulated(model, eng)
-        grads = eng.backward(g, gen=ctx.gen)
+        if torch.is_tensor(ctx.weights):  # (the engine's first launch forms the seed from the device-resident weights)
+            grads = eng.backward(eng.buf("gseed", (4,)), gen=ctx.gen, seed=(up, ctx.weights))
+        else:
+            grads = eng.backward(ops.scale4(up, ctx.weights, eng.buf("gseed", (4,))), gen=ctx.gen)
         return (None, None, None, None, None) + _hand_over(model, eng, grads)
 
 

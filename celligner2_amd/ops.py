@@ -805,6 +805,23 @@ def axpy(x, a_dev, y):
     check(lib.c2_axpy(ptr(x), ptr(a_dev), ptr(y), x.numel(), stream()))
 
 
+def scale4_dev_scale2(g_dev, w_dev, out4, jobs):
+    """scale4_dev plus up to two vectors scaled by out4[0] in the same launch: jobs = [(x, y), ...] -> y = out4[0] * x."""
+    L.require_gpu(w_dev, out4)
+    assert w_dev.dtype == torch.float32 and w_dev.numel() == 4 and out4.dtype == torch.float32 and out4.numel() == 4
+    assert len(jobs) <= 2
+    args = []
+    for x, y in list(jobs) + [(None, None)] * (2 - len(jobs)):
+        if x is None:
+            args += [None, None, 0]
+            continue
+        assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+        assert x.numel() == y.numel()
+        args += [ptr(x), ptr(y), x.numel()]
+    check(lib.c2_scale4_dev_scale2(ptr(g_dev), ptr(w_dev), ptr(out4), *args, stream()))
+    return out4
+
+
 def dropout_masks(out, p_drop, seed, offset):
     """Fill the flat uint8 buffer `out` with keep-masks (1 = keep)."""
     L.require_gpu(out)

@@ -448,6 +448,12 @@ int c2_scale4(const float* g_dev, float w0, float w1, float w2, float w3, float*
  * running sums of an epoch's loss logs (trainer.py:326-328 takes their float64 means) without a host read per step. */
 int c2_combine_losses_dev(const float* losses4, const float* w_dev, float* out6, double* accum6, void* stream);
 int c2_scale4_dev(const float* g_dev, const float* w_dev, float* out4, void* stream);
+/* c2_scale4_dev and the first two uses of its out4[0] (the upstream gradient of the reconstruction term) in one launch:
+ * y1[0..n1) = out4[0] * x1, y2[0..n2) = out4[0] * x2 -- the output layer's bias gradient and the dispersion gradient from
+ * the unit-upstream sums c2_recon_nb_fwd_bwd_dbias leaves (autograd of losses.py:27-65 scales them the same way).  Either
+ * vector may be absent (n = 0). */
+int c2_scale4_dev_scale2(const float* g_dev, const float* w_dev, float* out4, const float* x1, float* y1, int64_t n1,
+                         const float* x2, float* y2, int64_t n2, void* stream);
 
 /* c2_dropout_masks with the Philox counter offset in device memory: masks from *offset_dev + lead, then
  * *offset_dev += advance (a second, one-thread launch), so that every replay of a captured step draws fresh masks.

@@ -110,6 +110,24 @@ def test_combine_and_scale4_with_device_weights_are_the_by_value_kernels():
         assert torch.equal(x, y)
 
 
+def test_backward_seed_with_its_two_scaled_vectors_in_one_launch():
+    """c2_scale4_dev_scale2 = c2_scale4_dev followed by two c2_scale launches with out4[0], bit for bit."""
+    from celligner2_amd import ops
+    dev = "cuda"
+    w = torch.tensor([0.75, 1e-3, 2.0, 0.5], device=dev)
+    x1, x2 = torch.randn(19001, device=dev), torch.randn(19000 * 3, device=dev)
+    for up in (None, torch.tensor(0.25, device=dev)):
+        ref4 = ops.scale4_dev(up, w, torch.empty(4, device=dev))
+        r1, r2 = torch.empty_like(x1), torch.empty_like(x2)
+        ops.scale(x1, ref4[0:1], r1)
+        ops.scale(x2, ref4[0:1], r2)
+        for jobs in ([(x1, torch.empty_like(x1)), (x2, torch.empty_like(x2))], [(x2, torch.empty_like(x2))], []):
+            got4 = ops.scale4_dev_scale2(up, w, torch.empty(4, device=dev), jobs)
+            assert torch.equal(got4, ref4)
+            for (x, y) in jobs:
+                assert torch.equal(y, r1 if x is x1 else r2)
+
+
 def test_dropout_masks_with_a_device_counter_continue_the_host_counters_stream():
     from celligner2_amd import ops
     n = 16 * 1000 + 5
