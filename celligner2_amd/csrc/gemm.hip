@@ -306,16 +306,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 // reference's default batch of 128): one thread per output element, plain fp32 FMAs.  The tiled kernels spend 12-16 us on
 // such a launch (a 128x128 tile's prologue and epilogue around one or two K-steps); this one is bound by the launch itself.
 // Exact fp32 products, so it also serves the bf16x3 dtype (an approximation of the same thing).
-constexpr int64_t kTinyMacs = 1 << 21;
+static int64_t tiny_macs() {  // C2_GEMM_TINY_MACS: the threshold, for measurements (default 2^22 multiply-adds: 128 x 128 x 256)
+    static const int64_t v = [] {
+        const char* e = getenv("C2_GEMM_TINY_MACS");
+        return e ? (int64_t)atoll(e) : (int64_t)(1 << 22);
+    }();
+    return v;
+}
+#define kTinyMacs tiny_macs()
 // Eight lanes share one output element: each walks every eighth reduction index (so 16 384 outputs are 2048 waves, not 256,
 // and the serial chain of a 128-long reduction is 16 loads deep, not 128), then three shuffle steps add the eight partial sums.
 template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a) {
-    const int64_t idx = (blockIdx.x * 256ll + threadIdx.x) >> 3;
+__device__ __forceinline__ void gemm_tiny_body(const GemmArgs& a, int64_t block, int split) {
+    const int64_t idx = (block * 256ll + threadIdx.x) >> 3;
     const int sub = threadIdx.x & 7;
     const bool live = idx < (int64_t)a.M * a.N;
     const int m = live ? (int)(idx / a.N) : 0, n = live ? (int)(idx - (int64_t)m * a.N) : 0;
-    const int split = blockIdx.y;
     const int rbeg = split * a.r_per_split, rend = min(a.R, rbeg + a.r_per_split);
     const float* A = reinterpret_cast<const float*>(a.A);
     const float* B = reinterpret_cast<const float*>(a.B);
@@ -348,6 +354,16 @@ __global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a) {
     const float v = alpha * acc + add;
     if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)m * a.ldc + n] = (f16_t)v;
     else C[(int64_t)m * a.ldc + n] = v;
+}
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(GemmArgs a) {
+    gemm_tiny_body<A_RC, B_RC>(a, blockIdx.x, blockIdx.y);
+}
+// The two GEMMs of a tiny layer's backward pass -- input gradient (dY W) and weight gradient (dY^T A) -- in one launch: the
+// first nb0 blocks work on the one, the rest on the other (each a launch-bound kernel of its own before).
+__global__ __launch_bounds__(256) void gemm_tiny_pair_kernel(GemmArgs dgrad, GemmArgs wgrad, int nb0) {
+    if ((int)blockIdx.x < nb0) gemm_tiny_body<true, false>(dgrad, blockIdx.x, 0);
+    else gemm_tiny_body<false, false>(wgrad, blockIdx.x - nb0, 0);
 }
 static bool tiny_on() {
     static const bool on = [] { const char* e = getenv("C2_GEMM_TINY"); return !(e && e[0] == '0'); }();
@@ -689,6 +705,25 @@ extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int6
         a.B_lo = (const bf16_t*)A + M * lda;
     }
     C2_CHECK(gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_bwd_tiny(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* A, int64_t lda,
+                                  int64_t M, int64_t N, int64_t K, float* dA, int64_t ldda, float* dW, int64_t lddw,
+                                  const float* alpha_dev, void* stream) {
+    C2_CHECK(dY && W && A && dA && dW, "null pointer");
+    C2_CHECK(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bad shape");
+    C2_CHECK(lddy >= N && ldw >= K && lda >= K && ldda >= K && lddw >= K, "leading dimension too small");
+    C2_CHECK(c2_gemm_is_tiny(M, K, N) && c2_gemm_is_tiny(N, K, M), "not a tiny problem (c2_gemm_is_tiny)");
+    // dA[m][k] = sum_n dY[m][n] W[n][k]  (A-op dY row-wise, B-op W with the output index contiguous)
+    GemmArgs dg{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, 0, (int)M, (int)K, (int)N, 0, nullptr, nullptr, nullptr};
+    // dW[n][k] = sum_m dY[m][n] A[m][k]  (both operands with the output index contiguous)
+    GemmArgs wg{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, 0, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
+    dg.r_per_split = (int)N;
+    wg.r_per_split = (int)M;
+    const int nb0 = (int)((M * K * 8 + 255) / 256), nb1 = (int)((N * K * 8 + 255) / 256);
+    hipLaunchKernelGGL(gemm_tiny_pair_kernel, dim3(nb0 + nb1), dim3(256), 0, (hipStream_t)stream, dg, wg, nb0);
     C2_LAUNCH_CHECK();
     return 0;
 }

@@ -768,15 +768,20 @@ class StepEngine:
         need_b = blk.b is not None and self.p[blk.b].requires_grad
         need_c = blk.wc is not None and self.p[blk.wc].requires_grad
         # the activation gradient first (the chain every later launch of this pass waits for) ...
+        centred = blk is self.enc[0] and self._center is not None and need_w
+        paired = False
         if need_da:
             K = self.p[blk.w].shape[1]
             if out_slabs is None:
                 out_slabs = self.buf(blk.name + ".da", (self._dgrad_nslab(dh, blk.w), B, K))
-            self._dgrad(dh, blk.w, out_slabs)
+            # a tiny layer (the classifier, the decoder's first layer at the reference's batch of 128): input gradient and
+            # weight gradient in ONE launch
+            paired = need_w and not centred and self._tiny_pair(dh, a_in, blk.w, out_slabs)
+            if not paired:
+                self._dgrad(dh, blk.w, out_slabs)
         # ... then the parameter gradients, which only the optimizer waits for.
         # A centred first layer: dW = dh^T (x - c) + (sum_b dh_b) (x) c -- the column sums of dh (the bias gradient) come
         # first, the rank-one term rides in the weight-gradient GEMM's epilogue
-        centred = blk is self.enc[0] and self._center is not None and need_w
         with self._param_side():
             db = None
             if need_b or need_c or centred:
@@ -784,9 +789,24 @@ class StepEngine:
                 ws = self.buf("bcg.ws", (ops.bias_cond_grad_ws(B, H, C),))
                 db = self.gbuf(blk.b) if need_b else (self.buf("enc0.dhsum", (H,)) if centred else None)
                 ops.bias_cond_grad(dh, cond if need_c else None, db, self.gbuf(blk.wc) if need_c else None, ws)
-            if need_w:
+            if need_w and not paired:
                 self._wgrad(dh, a_in, blk.w, rank1=(db, self._center) if centred else None)
         return out_slabs if need_da else None
+
+    def _tiny_pair(self, dh, a_in, wname, out_slabs):
+        """Both GEMMs of a layer's backward pass in one launch when both are tiny fp32 problems with unsplit outputs
+        (c2_linear_bwd_tiny); False: not such a layer, nothing launched."""
+        if isinstance(a_in, (tuple, _T)) or out_slabs.shape[0] != 1:
+            return False
+        w = self.weight(wname)
+        B, H = dh.shape
+        K = w.shape[1]
+        if not (dh.dtype == F32 and a_in.dtype == F32 and w.dtype == F32 and tuple(a_in.shape) == (B, K) and B > 0
+                and ops.gemm_is_tiny(B, K, H) and ops.gemm_is_tiny(H, K, B)
+                and ops.pick_nslab(H, K, B, F32, self.x3, planes=False) == 1):
+            return False
+        ops.linear_bwd_tiny(dh, w, a_in, out_slabs[0], self.gbuf(wname))
+        return True
 
     def _partition(self, cond_all, status):
         """Partition ids of the batch's condition rows + the pair-weight table of the MMD (losses.py:202-249)."""

@@ -309,6 +309,18 @@ def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False, rank1=None):
     return dw
 
 
+def linear_bwd_tiny(dy, w, a, da, dw, alpha=None):
+    """da = alpha * dy @ w and dw = alpha * dy.T @ a in one launch (fp32, both problems tiny: gemm_is_tiny).
+    dy [M,N], w [N,K], a [M,K], da [M,K], dw [N,K]."""
+    L.require_gpu(dy, w, a, da, dw)
+    M, N = dy.shape
+    K = w.shape[1]
+    assert tuple(w.shape) == (N, K) and tuple(a.shape) == (M, K) and tuple(da.shape) == (M, K) and tuple(dw.shape) == (N, K)
+    assert all(t.dtype == torch.float32 for t in (dy, w, a, da, dw))
+    check(lib.c2_linear_bwd_tiny(ptr(dy), _row_major(dy, "dy"), ptr(w), _row_major(w, "w"), ptr(a), _row_major(a, "a"),
+                                 M, N, K, ptr(da), _row_major(da, "da"), ptr(dw), _row_major(dw, "dw"), ptr(alpha), stream()))
+
+
 def sum_slabs(slabs, out):
     n = out.numel()
     assert slabs.is_contiguous() and out.is_contiguous() and slabs.numel() == slabs.shape[0] * n

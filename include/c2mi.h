@@ -143,6 +143,14 @@ int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R);
  * most 2^21 multiply-adds): a caller that would split such operands into bf16 planes (C2_BF16X3P) should not. */
 int c2_gemm_is_tiny(int64_t M, int64_t N, int64_t R);
 
+/* Input gradient and weight gradient of ONE tiny fp32 layer in one launch (no counterpart in the reference, whose autograd
+ * launches the two GEMMs of nn.Linear's backward, modules.py:77-107, separately):  dA[M,K] = alpha * dY[M,N] W[N,K] and
+ * dW[N,K] = alpha * dY^T A[M,K], alpha = *alpha_dev (1 when NULL).  Both problems must pass c2_gemm_is_tiny; same
+ * arithmetic as c2_linear_dgrad / c2_linear_wgrad on such problems, bit for bit. */
+int c2_linear_bwd_tiny(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* A, int64_t lda, int64_t M,
+                       int64_t N, int64_t K, float* dA, int64_t ldda, float* dW, int64_t lddw, const float* alpha_dev,
+                       void* stream);
+
 /* fp32 [rows, cols] -> two bf16 planes dst[0] = hi = bf16(x), dst[1] = lo = bf16(x - hi); dst is [2][rows][ldd].
  * Producer side of C2_BF16X3P (no counterpart in the reference, which multiplies in fp32). */
 int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd, void* stream);

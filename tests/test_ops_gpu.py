@@ -26,6 +26,31 @@ def rel(a, b):
     return gu.relerr(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (128, 30, 64), (37, 33, 7), (1, 5, 3), (128, 128, 16)])
+def test_tiny_layer_backward_in_one_launch(M, N, K):
+    """c2_linear_bwd_tiny = c2_linear_dgrad + c2_linear_wgrad on tiny fp32 problems, bit for bit (strided operands too),
+    and right against float64; a problem that is not tiny is refused."""
+    ops = _ops()
+    rng = np.random.default_rng(M + 3 * N + 5 * K)
+    dy = T(rng.standard_normal((M, N + 3)).astype(np.float32))[:, :N]   # (row pitch > width)
+    w = T(rng.standard_normal((N, K)).astype(np.float32))
+    a = T(rng.standard_normal((M, K + 1)).astype(np.float32))[:, :K]
+    assert ops.gemm_is_tiny(M, K, N) and ops.gemm_is_tiny(N, K, M)
+    for alpha in (None, T(np.array([0.25], np.float32))):
+        da0, dw0 = torch.empty(M, K, device=DEV), torch.empty(N, K, device=DEV)
+        ops.linear_dgrad(dy, w, da0, alpha=alpha)
+        ops.linear_wgrad(dy, a, dw0, alpha=alpha)
+        da1, dw1 = torch.full((M, K), float("nan"), device=DEV), torch.full((N, K), float("nan"), device=DEV)
+        ops.linear_bwd_tiny(dy, w, a, da1, dw1, alpha=alpha)
+        assert torch.equal(da0, da1) and torch.equal(dw0, dw1)
+        s = 1.0 if alpha is None else 0.25
+        assert rel(da1, s * dy.double().cpu().numpy() @ w.double().cpu().numpy()) < 1e-5
+        assert rel(dw1, s * dy.double().cpu().numpy().T @ a.double().cpu().numpy()) < 1e-5
+    big = T(np.zeros((512, 512), np.float32))
+    with pytest.raises(Exception):
+        ops.linear_bwd_tiny(big, big, big, torch.empty(512, 512, device=DEV), torch.empty(512, 512, device=DEV))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2), (torch.float16, 1e-3)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 19000), (37, 300, 130), (4, 19000, 16), (512, 1000, 515)])
 def test_linear_three_layouts(dtype, tol, M, N, K):

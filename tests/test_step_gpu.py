@@ -332,7 +332,7 @@ def test_bf16_operand_copies_follow_the_optimizer():
         opt.zero_grad()
         eng = m._engine()
         params = dict(m.named_parameters())
-        assert len(eng._wplanes) >= 4 and len(eng._shadow) == 2
+        assert len(eng._wplanes) >= 3 and len(eng._shadow) == 2  # (the decoder's 64 -> 256 layer at 256 rows is a tiny GEMM: no planes)
         for n, sh in eng._shadow.items():
             assert torch.equal(sh, params[n].detach().to(sh.dtype)), (n, step)
         for n, (_, pl) in eng._wplanes.items():
