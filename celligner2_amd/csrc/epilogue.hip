@@ -1517,6 +1517,11 @@ extern "C" int c2_scale4_dev_scale2(const float* g_dev, const float* w_dev, floa
     return 0;
 }
 
+static int noise_grid_cap() {  // C2_NOISE_GRID: blocks of the noise launch at most (each takes one ticket: same-address atomics serialise)
+    static const int v = [] { const char* e = getenv("C2_NOISE_GRID"); return e ? std::max(1, atoi(e)) : 256; }();
+    return v;
+}
+
 extern "C" int c2_noise_dev(uint8_t* masks, int64_t n_mask, float p_drop, float* eps, int64_t n_eps, uint64_t eps_first,
                             uint64_t seed, uint64_t* state, uint64_t lead, uint64_t advance, void* stream) {
     C2_CHECK(state && n_mask >= 0 && n_eps >= 0 && (n_mask == 0 || masks) && (n_eps == 0 || eps), "null pointer or negative count");
@@ -1525,7 +1530,7 @@ extern "C" int c2_noise_dev(uint8_t* masks, int64_t n_mask, float p_drop, float*
     if (n_mask == 0 && n_eps == 0 && advance == 0) return 0;
     const unsigned thresh8 = (unsigned)lrintf(p_drop * 256.f);
     const int64_t work = std::max<int64_t>((n_mask + 15) / 16, (n_eps + 3) / 4 + 1);
-    hipLaunchKernelGGL(noise_dev_kernel, dim3(grid_for(work, 256, 1024)), dim3(256), 0, (hipStream_t)stream, masks, n_mask, thresh8, eps,
+    hipLaunchKernelGGL(noise_dev_kernel, dim3(grid_for(work, 256, noise_grid_cap())), dim3(256), 0, (hipStream_t)stream, masks, n_mask, thresh8, eps,
                        n_eps, (unsigned long long)eps_first, (unsigned long long)seed, (unsigned long long*)state,
                        (unsigned long long)lead, (unsigned long long)advance);
     C2_LAUNCH_CHECK();
