@@ -125,6 +125,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // Deterministic second stage of a loss reduction: one block sums `n` partials and ADDS to *out.
 int launch_finalize_sum(const float* partials, int n, float* out, hipStream_t stream);
+bool set_defer_sums(bool on);  // (epilogue.hip) deferral of those sums for this thread, on / off; returns what it was
 
 constexpr int kReduceWsFloats = 8192;  // max partials of a two-stage loss reduction
 

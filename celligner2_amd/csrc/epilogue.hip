@@ -32,6 +32,14 @@ struct PendingSums {
 static thread_local bool g_defer_sums = false;
 static thread_local PendingSums g_pending_sums = {};
 
+// Suspend / resume deferral for the calling thread without touching what already waits (callers whose partials do not
+// outlive the call: c2_mmd_fwd_bwd_static, whose scratch the next static call overwrites).  Returns the previous state.
+bool set_defer_sums(bool on) {
+    const bool was = g_defer_sums;
+    g_defer_sums = on;
+    return was;
+}
+
 int launch_finalize_sum(const float* partials, int n, float* out, hipStream_t stream) {
     if (g_defer_sums && g_pending_sums.count < kMaxPendingSums) {
         PendingSums& p = g_pending_sums;

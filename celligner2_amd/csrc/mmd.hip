@@ -960,5 +960,10 @@ extern "C" int c2_mmd_fwd_bwd_static(const void* feat, int f_dtype, int64_t ldf,
     if (int rc = scratch_on_current_device(&ws)) return rc;
     // Nothing of the array has to start at zero: row norms [Bg], loss partials [nit*jsplit] and gradient slabs
     // [jsplit][Bl][D] are each fully written by this call's kernels before its reducing kernels read them.
-    return mmd_run(feat, f_dtype, ldf, part_id, wt, row0, Bl, Bg, D, beta, loss_out, dfeat, lddf, ws, stream);
+    // (its loss partials live in the shared array, which the next call on this GPU overwrites: their sum is launched
+    // here, never left to a later combine launch -- c2_defer_loss_sums does not apply to this entry point)
+    const bool was = set_defer_sums(false);
+    const int rc = mmd_run(feat, f_dtype, ldf, part_id, wt, row0, Bl, Bg, D, beta, loss_out, dfeat, lddf, ws, stream);
+    set_defer_sums(was);
+    return rc;
 }

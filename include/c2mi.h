@@ -311,7 +311,9 @@ int c2_mmd_fwd_bwd(const void* feat, int f_dtype, int64_t ldf, const int32_t* pa
  * Same arguments, results bit-identical to c2_mmd_fwd_bwd.  Sizes whose c2_mmd_ws(Bl,Bg,D) exceeds
  * C2_MMD_STATIC_FLOATS are rejected with an error (e.g. 512 x 512 rows x 64 features or 1024 x 1024 x 16 fit, 4096 x
  * 4096 x 64 does not).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
- * host threads) race; calls on one stream are ordered and safe.  Calls no hipMalloc / hipFree and launches on `stream`. */
+ * host threads) race; calls on one stream are ordered and safe.  Calls no hipMalloc / hipFree and launches on `stream`.
+ * c2_defer_loss_sums does not apply here: the loss partials live in the shared array, so their sum is always launched by
+ * this call (loss_out is complete in stream order when it returns). */
 #define C2_MMD_STATIC_FLOATS (1u << 20)
 size_t c2_mmd_static_floats(void);
 int c2_mmd_fwd_bwd_static(const void* feat, int f_dtype, int64_t ldf, const int32_t* part_id, const float* wt,

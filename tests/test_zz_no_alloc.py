@@ -93,3 +93,24 @@ def test_static_scratch_mmd_rejects_sizes_beyond_the_array():
     with pytest.raises(C2Error, match="C2_MMD_STATIC_FLOATS"):
         ops.mmd_static(feat, part, wt, 0, B, 1.0, loss, d)
     assert loss.item() == 0.0  # nothing was launched
+
+
+def test_static_scratch_mmd_sums_its_loss_itself_while_sums_are_deferred():
+    """c2_defer_loss_sums leaves the loss kernels' second stages to the next combine launch -- but the static entry point's
+    partials live in the shared array, which the next static call overwrites: it always launches its own sum."""
+    from celligner2_amd import ops
+    a, b = _case(ops, 200, 32, 3, 9), _case(ops, 136, 16, 3, 10)
+    ref = []
+    for c in (a, b):
+        ops.mmd(c["feat"], c["part"], c["wt"], 0, c["B"], 2.0, c["loss_a"], c["d_a"], c["ws"])
+        ref.append(c["loss_a"].clone())
+    ops.defer_loss_sums(True)
+    try:
+        for c in (a, b):  # two static calls in a row, nothing combined in between
+            ops.mmd_static(c["feat"], c["part"], c["wt"], 0, c["B"], 2.0, c["loss_b"], c["d_b"])
+    finally:
+        ops.defer_loss_sums(False)
+        ops.drop_pending_sums()
+    torch.cuda.synchronize()
+    assert torch.equal(a["loss_b"], ref[0]) and torch.equal(b["loss_b"], ref[1])
+    assert torch.equal(a["d_b"], a["d_a"]) and torch.equal(b["d_b"], b["d_a"])
