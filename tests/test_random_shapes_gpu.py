@@ -157,3 +157,39 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     assert leg["x_full"].stride(0) == G4 and "_rows4" in plain.__dict__
     v2, _ = step(leg)
     assert torch.allclose(v2, v0, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("L,mmd_on", [(26, "z"), (10, "z"), (7, "z"), (12, "y")])
+def test_mmd_at_a_feature_width_that_is_not_a_multiple_of_4(L, mmd_on):
+    """The MMD's four-wave kernel reads 16-byte feature chunks; a latent width like the reference's 26 (or its default 10) is
+    widened with zero columns inside the engine (engine._forward) instead of falling to the general pair-tile kernel.  Same
+    loss and gradients as the general kernel on the unpadded features (C2_ROWS4=0 / engine.rows4_on), two summation orders."""
+    import torch
+    from celligner2_amd.model import Celligner2
+    G, B, C = 256, 192, 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(L)
+    x = torch.poisson(torch.full((B, G), 2.0, device="cuda"), generator=g)
+    cond = torch.zeros(B, C, dtype=torch.int64, device="cuda")
+    cond[torch.arange(B, device="cuda"), torch.randint(0, C, (B,), device="cuda", generator=g)] = 1
+    eps = torch.randn(B, L, device="cuda", generator=g)
+    torch.manual_seed(2)
+    hidden = [64, 50] if mmd_on == "y" else [64, 32]   # (mmd_on='y': the decoder's first layer's output, 50 wide here)
+    m = Celligner2(G, hidden, L, 0.0, False, "nb", conditions=["a", "b", "c"], use_mmd=True, mmd_on=mmd_on, beta=20.0).cuda().train()
+    eng = m._engine()
+    out = {}
+    for fast in (True, False):
+        eng.rows4_on = fast
+        m._forced_noise = dict(eps=eps, masks={})
+        for p in m.parameters():
+            p.grad = None
+        r, k, mm, ce = m(x=x, batch=cond, sizefactor=x.sum(1))
+        (r + 1e-3 * k + mm + ce).backward()
+        eng.check_status()
+        out[fast] = (mm.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    eng.rows4_on = True
+    assert ("mmd.feat4" in eng._ws) == ((L if mmd_on == "z" else hidden[-1]) % 4 != 0)
+    assert abs(out[True][0] - out[False][0]) <= 2e-5 * max(abs(out[False][0]), 1e-3), (out[True][0], out[False][0])
+    for n, g0 in out[False][1].items():
+        e = float((out[True][1][n].double() - g0.double()).norm() / g0.double().norm().clamp_min(1e-30))
+        assert e < 2e-4, (n, e)
