@@ -99,6 +99,10 @@ _SIGS = {
     "c2_scale4_dev": (i32, [vp, vp, vp, vp]),
     "c2_dropout_masks_dev": (i32, [vp, i64, f32, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp]),
     "c2_scale4_dev_scale2": (i32, [vp, vp, vp, vp, vp, i64, vp, vp, i64, vp]),
+    "c2_split_bf16_planes": (i32, [vp, i64, i64, i64, vp, vp, i64, vp]),
+    "c2_linear_fwd_planes": (i32, [vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_dgrad_planes": (i32, [vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp]),
+    "c2_linear_wgrad_planes": (i32, [vp, vp, i64, vp, vp, i64, i64, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]),
     "c2_linear_bwd_tiny": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp, i64, vp, vp]),
     "c2_noise_dev": (i32, [vp, i64, f32, vp, i64, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp]),
     "c2_graph_launch": (i32, [vp, vp]),

@@ -503,8 +503,7 @@ extern "C" int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R) {
 }
 
 __global__ void split_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
-                                  bf16_t* __restrict__ dst, int64_t ldd, bool vec) {
-    const int64_t plane = rows * ldd;
+                                  bf16_t* __restrict__ dst, int64_t ldd, bool vec, int64_t plane) {
     if (vec) {
         const int64_t c4 = cols >> 2, n = rows * c4;
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -536,17 +535,45 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, int64_t rows, i
     }
 }
 
-extern "C" int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd,
-                             void* stream) {
-    C2_CHECK(src && dst, "null pointer");
+extern "C" int c2_split_bf16_planes(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_hi, void* dst_lo,
+                                    int64_t ldd, void* stream) {
+    C2_CHECK(src && dst_hi && dst_lo, "null pointer");
     C2_CHECK(rows >= 0 && cols >= 0 && ld >= cols && ldd >= cols, "bad shape");
     if (rows == 0 || cols == 0) return 0;
+    const int64_t plane = (const bf16_t*)dst_lo - (const bf16_t*)dst_hi;  // (elements; either sign)
     const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && (ldd % 4 == 0) && aligned16(src) &&
-                     ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) && ((rows * ldd) % 4 == 0);
+                     ((reinterpret_cast<uintptr_t>(dst_hi) & 7) == 0) && ((reinterpret_cast<uintptr_t>(dst_lo) & 7) == 0);
     const int64_t n = vec ? rows * (cols / 4) : rows * cols;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, rows, cols, ld,
-                       (bf16_t*)dst, ldd, vec);
+                       (bf16_t*)dst_hi, ldd, vec, plane);
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd,
+                             void* stream) {
+    C2_CHECK(src && dst, "null pointer");
+    return c2_split_bf16_planes(src, rows, cols, ld, dst, (bf16_t*)dst + rows * ldd, ldd, stream);
+}
+
+// (A_lo / W_lo: the low planes of C2_BF16X3P operands; NULL = directly behind the high plane, rows x ld elements on)
+static int linear_fwd_impl(const char* fn, const void* A, const void* A_lo, int64_t lda, const void* W, const void* W_lo,
+                           int64_t ldw, int dtype, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
+                           int64_t slab_stride, const float* bias, void* stream) {
+#define C2_CHECK_FN(cond, msg) do { if (!(cond)) { c2::set_error(std::string(fn) + ": " + (msg)); return 1; } } while (0)
+    C2_CHECK_FN(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK_FN(A && W && Y, "null pointer");
+    C2_CHECK_FN(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
+    C2_CHECK_FN(!(bias && nslab != 1), "bias needs nslab == 1");
+    C2_CHECK_FN(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr, nullptr};
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = A_lo ? A_lo : (const void*)((const bf16_t*)A + M * lda);
+        a.B_lo = W_lo ? W_lo : (const void*)((const bf16_t*)W + N * ldw);
+    }
+    C2_CHECK_FN(gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -554,20 +581,15 @@ extern "C" int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64
 extern "C" int c2_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
                              int64_t K, float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                              void* stream) {
-    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
-    C2_CHECK(A && W && Y, "null pointer");
-    C2_CHECK(lda >= K && ldw >= K && ldy >= N, "leading dimension too small");
-    C2_CHECK(!(bias && nslab != 1), "bias needs nslab == 1");
-    C2_CHECK(nslab == 1 || slab_stride >= M * ldy, "slab_stride too small");
-    if (M == 0 || N == 0) return 0;
-    GemmArgs a{A, W, Y, bias, nullptr, lda, ldw, ldy, slab_stride, (int)M, (int)N, (int)K, 0, nullptr, nullptr, nullptr};
-    if (dtype == C2_BF16X3P) {
-        a.A_lo = (const bf16_t*)A + M * lda;
-        a.B_lo = (const bf16_t*)W + N * ldw;
-    }
-    C2_CHECK(gemm_dispatch(0, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
-    C2_LAUNCH_CHECK();
-    return 0;
+    return linear_fwd_impl(__func__, A, nullptr, lda, W, nullptr, ldw, dtype, M, N, K, Y, ldy, nslab, slab_stride, bias, stream);
+}
+
+extern "C" int c2_linear_fwd_planes(const void* A_hi, const void* A_lo, int64_t lda, const void* W_hi, const void* W_lo,
+                                    int64_t ldw, int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab,
+                                    int64_t slab_stride, const float* bias, void* stream) {
+    C2_CHECK(A_lo && W_lo, "null pointer");
+    return linear_fwd_impl(__func__, A_hi, A_lo, lda, W_hi, W_lo, ldw, C2_BF16X3P, M, N, K, Y, ldy, nslab, slab_stride, bias,
+                           stream);
 }
 
 extern "C" int c2_linear_fwd_f16out(const void* A, int64_t lda, const void* W, int64_t ldw, int dtype, int64_t M, int64_t N,
@@ -669,21 +691,58 @@ extern "C" int c2_linear_wgrad_bt(const void* dY, int64_t lddy, const void* At, 
     return 0;
 }
 
-extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, int dtype, int64_t M,
-                               int64_t N, int64_t K, float* dA, int64_t ldda, int nslab, int64_t slab_stride,
-                               const float* alpha_dev, void* stream) {
-    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
-    C2_CHECK(dY && W && dA, "null pointer");
-    C2_CHECK(lddy >= N && ldw >= K && ldda >= K, "leading dimension too small");
-    C2_CHECK(nslab == 1 || slab_stride >= M * ldda, "slab_stride too small");
+static int linear_dgrad_impl(const char* fn, const void* dY, const void* dY_lo, int64_t lddy, const void* W, const void* W_lo,
+                             int64_t ldw, int dtype, int64_t M, int64_t N, int64_t K, float* dA, int64_t ldda, int nslab,
+                             int64_t slab_stride, const float* alpha_dev, void* stream) {
+    C2_CHECK_FN(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK_FN(dY && W && dA, "null pointer");
+    C2_CHECK_FN(lddy >= N && ldw >= K && ldda >= K, "leading dimension too small");
+    C2_CHECK_FN(nslab == 1 || slab_stride >= M * ldda, "slab_stride too small");
     if (M == 0 || K == 0) return 0;
     // C[m][k] = sum_n dY[m][n] W[n][k]:  A-op = dY (RC over n), B-op = W ([n][k]: XC, output index k contiguous)
     GemmArgs a{dY, W, dA, nullptr, alpha_dev, lddy, ldw, ldda, slab_stride, (int)M, (int)K, (int)N, 0, nullptr, nullptr, nullptr};
     if (dtype == C2_BF16X3P) {
-        a.A_lo = (const bf16_t*)dY + M * lddy;
-        a.B_lo = (const bf16_t*)W + N * ldw;
+        a.A_lo = dY_lo ? dY_lo : (const void*)((const bf16_t*)dY + M * lddy);
+        a.B_lo = W_lo ? W_lo : (const void*)((const bf16_t*)W + N * ldw);
     }
-    C2_CHECK(gemm_dispatch(1, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_CHECK_FN(gemm_dispatch(1, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
+    C2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int64_t ldw, int dtype, int64_t M,
+                               int64_t N, int64_t K, float* dA, int64_t ldda, int nslab, int64_t slab_stride,
+                               const float* alpha_dev, void* stream) {
+    return linear_dgrad_impl(__func__, dY, nullptr, lddy, W, nullptr, ldw, dtype, M, N, K, dA, ldda, nslab, slab_stride,
+                             alpha_dev, stream);
+}
+
+extern "C" int c2_linear_dgrad_planes(const void* dY_hi, const void* dY_lo, int64_t lddy, const void* W_hi, const void* W_lo,
+                                      int64_t ldw, int64_t M, int64_t N, int64_t K, float* dA, int64_t ldda, int nslab,
+                                      int64_t slab_stride, const float* alpha_dev, void* stream) {
+    C2_CHECK(dY_lo && W_lo, "null pointer");
+    return linear_dgrad_impl(__func__, dY_hi, dY_lo, lddy, W_hi, W_lo, ldw, C2_BF16X3P, M, N, K, dA, ldda, nslab, slab_stride,
+                             alpha_dev, stream);
+}
+
+static int linear_wgrad_impl(const char* fn, const void* dY, const void* dY_lo, int64_t lddy, const void* A, const void* A_lo,
+                             int64_t lda, int dtype, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
+                             int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col,
+                             void* stream) {
+    C2_CHECK_FN(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
+    C2_CHECK_FN(dY && A && dW, "null pointer");
+    C2_CHECK_FN(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
+    C2_CHECK_FN(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
+    if (N == 0 || K == 0) return 0;
+    // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
+    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
+    C2_CHECK_FN(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
+    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
+    if (dtype == C2_BF16X3P) {
+        a.A_lo = dY_lo ? dY_lo : (const void*)((const bf16_t*)dY + M * lddy);
+        a.B_lo = A_lo ? A_lo : (const void*)((const bf16_t*)A + M * lda);
+    }
+    C2_CHECK_FN(gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
     C2_LAUNCH_CHECK();
     return 0;
 }
@@ -691,22 +750,17 @@ extern "C" int c2_linear_dgrad(const void* dY, int64_t lddy, const void* W, int6
 extern "C" int c2_linear_wgrad(const void* dY, int64_t lddy, const void* A, int64_t lda, int dtype, int64_t M,
                                int64_t N, int64_t K, float* dW, int64_t lddw, int nslab, int64_t slab_stride,
                                const float* alpha_dev, const float* rank1_row, const float* rank1_col, void* stream) {
-    C2_CHECK(gemm_args_ok(dtype, M, N, K, nslab), "bad dtype/shape");
-    C2_CHECK(dY && A && dW, "null pointer");
-    C2_CHECK(lddy >= N && lda >= K && lddw >= K, "leading dimension too small");
-    C2_CHECK(nslab == 1 || slab_stride >= N * lddw, "slab_stride too small");
-    if (N == 0 || K == 0) return 0;
-    // C[n][k] = sum_m dY[m][n] A[m][k]:  A-op = dY ([m][n]: XC over n), B-op = A ([m][k]: XC over k)
-    GemmArgs a{dY, A, dW, nullptr, alpha_dev, lddy, lda, lddw, slab_stride, (int)N, (int)K, (int)M, 0, nullptr, nullptr, nullptr};
-    C2_CHECK(!rank1_row == !rank1_col, "rank1_row and rank1_col come together");
-    if (rank1_row) { a.rowscale = rank1_row; a.bias = rank1_col; }
-    if (dtype == C2_BF16X3P) {
-        a.A_lo = (const bf16_t*)dY + M * lddy;
-        a.B_lo = (const bf16_t*)A + M * lda;
-    }
-    C2_CHECK(gemm_dispatch(2, dtype, a, nslab, (hipStream_t)stream) == 0, "C2_BF16X3P: shape/alignment not supported");
-    C2_LAUNCH_CHECK();
-    return 0;
+    return linear_wgrad_impl(__func__, dY, nullptr, lddy, A, nullptr, lda, dtype, M, N, K, dW, lddw, nslab, slab_stride,
+                             alpha_dev, rank1_row, rank1_col, stream);
+}
+
+extern "C" int c2_linear_wgrad_planes(const void* dY_hi, const void* dY_lo, int64_t lddy, const void* A_hi, const void* A_lo,
+                                      int64_t lda, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
+                                      int64_t slab_stride, const float* alpha_dev, const float* rank1_row,
+                                      const float* rank1_col, void* stream) {
+    C2_CHECK(dY_lo && A_lo, "null pointer");
+    return linear_wgrad_impl(__func__, dY_hi, dY_lo, lddy, A_hi, A_lo, lda, C2_BF16X3P, M, N, K, dW, lddw, nslab, slab_stride,
+                             alpha_dev, rank1_row, rank1_col, stream);
 }
 
 extern "C" int c2_linear_bwd_tiny(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* A, int64_t lda,

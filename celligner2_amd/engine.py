@@ -344,12 +344,14 @@ class StepEngine:
         sh = self._shadow.get(name)
         if sh is not None:
             return sh if sh.is_contiguous() else None  # (a padded copy is refreshed by weight(), see there)
+        # (planes in padded storage -- a width that is not a multiple of 8 -- are not dense: the kernel's flat indexing
+        # does not apply, the engine splits such a weight again when its version has moved)
         c = self._wplanes.get(name)
         if c is not None:
-            return c[1]
+            return c[1] if c[1].is_contiguous() else None
         if name in (self.HEADS[0] + ".weight", self.HEADS[1] + ".weight"):
             c = self._wplanes.get(self.HEADW)  # rows [0,L) / [L,2L) of the stacked planes: (hi, lo) of this head
-            if c is not None:
+            if c is not None and c[1].is_contiguous():
                 L = self.p[name].shape[0]
                 k = 0 if name.startswith(self.HEADS[0]) else 1
                 return (c[1][0, k * L:(k + 1) * L], c[1][1, k * L:(k + 1) * L])
@@ -430,11 +432,21 @@ class StepEngine:
     # ------------------------------------------------------------------ helpers
     # bf16 mode, narrow (fp32-operand) GEMMs: both operands are split ONCE into bf16 planes (hi, lo) and multiplied
     # as three bf16 products by the LDS-DMA kernel (C2_BF16X3P); shapes it cannot take stay on the in-kernel split.
+    @staticmethod
+    def _r8(n):
+        return (int(n) + 7) // 8 * 8
+
     def _planes_of(self, t):
+        """(hi, lo) bf16 planes of this step's fp32 matrix t [rows, cols].  A width that is not a multiple of 8 gets planes
+        with the row pitch rounded up and zero pad columns (the LDS-DMA kernels move 16-byte chunks from 16-byte aligned
+        rows; a reduction over the padded width adds exact zeros): the [2, rows, cols] view of that storage is returned."""
         key = (t.data_ptr(), tuple(t.shape))
         pl = self._aplanes.get(key)
         if pl is None:
-            pl = ops.split_bf16(t, self.buf(("pl", len(self._aplanes)), (2,) + tuple(t.shape), torch.bfloat16))
+            rows, cols = t.shape
+            c8 = self._r8(cols)
+            full = self.buf(("pl", len(self._aplanes)), (2, rows, c8), torch.bfloat16, zero=c8 != cols)
+            pl = ops.split_bf16(t, full[:, :, :cols] if c8 != cols else full)
             self._aplanes[key] = pl
         return pl
 
@@ -448,31 +460,66 @@ class StepEngine:
         self._aplanes[(t.data_ptr(), (B, H))] = pl
         return pl
 
+    def _wplane_storage(self, shape, old):
+        """[2, N, K] planes of a weight, kept from `old` when that has the shape; a new one is a view of zero-filled
+        [2, N8, K8] storage when N or K is not a multiple of 8 (zero pad columns AND rows: the input gradient reduces
+        over the weight's rows)."""
+        if old is not None and old.shape[1:] == tuple(shape):
+            return old
+        N, K = shape
+        n8, k8 = self._r8(N), self._r8(K)
+        if (n8, k8) == (N, K):
+            return None  # (split_bf16 makes a dense one)
+        return torch.zeros((2, n8, k8), dtype=torch.bfloat16, device=self.dev)[:, :N, :K]
+
     def _wplanes_of(self, name):
         if name == self.HEADW:
             W, ver = self._ws["heads.W"], self._heads_version()
             c = self._wplanes.get(name)
             if c is None or c[0] != ver or c[1].shape[1:] != W.shape:
-                pl = c[1] if (c is not None and c[1].shape[1:] == W.shape) else None
-                c = (ver, ops.split_bf16(W, pl))
+                c = (ver, ops.split_bf16(W, self._wplane_storage(W.shape, c[1] if c is not None else None)))
                 self._wplanes[name] = c
             return c[1]
         p = self.p[name]
         c = self._wplanes.get(name)
         if c is None or c[0] != p._version or c[1].shape[1:] != p.shape:
-            pl = c[1] if (c is not None and c[1].shape[1:] == p.shape) else None
-            c = (p._version, ops.split_bf16(p.detach(), pl))
+            c = (p._version, ops.split_bf16(p.detach(), self._wplane_storage(p.shape, c[1] if c is not None else None)))
             self._wplanes[name] = c
         return c[1]
 
-    def _pair(self, x, y, M, N, R, wx=None, wy=None):
+    def _planes_fit(self, mode, M, N, R):
+        """Can the [M, N] GEMM reduced over R run on bf16 planes, and over which reduction length?  mode: "fwd" (both
+        operands reduced along their columns), "dgrad" (the first along its columns, the weight along its rows), "wgrad" (both
+        along their rows: the batch).  Returns the (padded) reduction length, or 0."""
+        r8 = self._r8
+        if not self.x3 or ops.gemm_is_tiny(M, N, R):
+            return 0
+        if mode == "wgrad":
+            if R % 8:
+                return 0
+            R8, lds = R, (r8(M), r8(N))
+        else:
+            R8 = r8(R)
+            lds = (R8, R8) if mode == "fwd" else (R8, r8(N))
+        return R8 if ops.planes_ok(M, N, R8, lds) else 0
+
+    def _pair(self, x, y, M, N, R, wx=None, wy=None, mode="fwd"):
         """Operand pair of one GEMM ([M,N] output reduced over R): planes when both are fp32 in bf16x3 mode and the
-        shape allows, else unchanged.  wx / wy: parameter name when that operand is a weight.  Returns (x, y, planes)."""
-        if not (self.x3 and x.dtype == F32 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous()
-                and not ops.gemm_is_tiny(M, N, R) and ops.planes_ok(M, N, R, (x.shape[1], y.shape[1]))):
+        shape allows, else unchanged.  wx / wy: parameter name when that operand is a weight; mode: see _planes_fit.
+        Returns (x, y, planes).  Where the reduction length is not a multiple of 8 the planes are handed over widened
+        over their zero pad (columns; the weight's rows in "dgrad")."""
+        if not (x.dtype == F32 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous()):
+            return x, y, False
+        R8 = self._planes_fit(mode, M, N, R)
+        if not R8:
             return x, y, False
         px = self._wplanes_of(wx) if wx else self._planes_of(x)
         py = self._wplanes_of(wy) if wy else self._planes_of(y)
+        if R8 != R:
+            cols = lambda pl: pl.as_strided((2, pl.shape[1], R8), pl.stride(), pl.storage_offset())  # noqa: E731
+            rows = lambda pl: pl.as_strided((2, R8, pl.shape[2]), pl.stride(), pl.storage_offset())  # noqa: E731
+            px = cols(px)
+            py = cols(py) if mode == "fwd" else rows(py)
         return px, py, True
 
     def _fwd(self, a, wname, y, bias=None):
@@ -499,13 +546,13 @@ class StepEngine:
             # reduction over a gene count that is not a multiple of 8: dy's pad columns and w's pad rows are zero
             dy = dy.as_strided((dy.shape[0], ld), (ld, 1), dy.storage_offset())
             w = w.as_strided((ld, w.shape[1]), (w.shape[1], 1), w.storage_offset())
-        d2, w2, _ = self._pair(dy, w, dy.shape[0], w.shape[1], w.shape[0], wy=wname)
+        d2, w2, _ = self._pair(dy, w, dy.shape[0], w.shape[1], w.shape[0], wy=wname, mode="dgrad")
         ops.linear_dgrad(d2, w2, out_slabs, nslab=out_slabs.shape[0], alpha=alpha, x3=self.x3)
 
     def _dgrad_nslab(self, dy, wname):
         w = self.weight(wname)
         M, K, R = dy.shape[0], w.shape[1], w.shape[0]
-        _, _, pl = self._pair(dy, w, M, K, R, wy=wname)
+        pl = dy.dtype == F32 and w.dtype == F32 and bool(self._planes_fit("dgrad", M, K, R))
         return ops.pick_nslab(M, K, R, dy.dtype, self.x3, planes=pl)
 
     def _linear_slabs(self, key, a, wname, B):
@@ -543,7 +590,7 @@ class StepEngine:
                     self._wg(dy, a, slabs, nslab=ns, alpha=alpha, rank1=rank1)
                     ops.sum_slabs(slabs, g)
             return
-        dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0])
+        dy2, a2, pl = self._pair(dy, a, N, K, dy.shape[0], mode="wgrad")
         if not pl:
             at = self._narrow_t(a, "at", N, K, dy)
             if self._wgrad_two_part(dy, at, g, alpha, rank1):
@@ -1183,8 +1230,7 @@ class StepEngine:
         # followed by one slab from the classifier branch; the reparameterisation backward sums them
         H0 = self.p[self.dec[0].w].shape[0]
         nz = ops.pick_nslab(B, L, H0, self.dec[0].gt, self.x3,
-                            planes=(self.x3 and self.dec[0].gt == F32 and not ops.gemm_is_tiny(B, L, H0)
-                                    and ops.planes_ok(B, L, H0, (H0, L))))
+                            planes=self.dec[0].gt == F32 and bool(self._planes_fit("dgrad", B, L, H0)))
         dz_all = self.buf("dz.all", (nz + n_cls_slab, B, L))
         on_y = cfg["use_mmd"] and cfg["mmd_on"] != "z"
         self._block_bwd(self.dec[0], dd, self._dec_in[0], cond, masks, True, out_slabs=dz_all[0:nz],

@@ -46,23 +46,30 @@ def _row_major(t, name):
 
 def _operand(t, name, x3):
     """(2-D shape, leading dimension, dtype code) of a GEMM operand: a row-major matrix, or the two bf16 planes
-    [2, rows, cols] (hi, lo) that split_bf16 makes of an fp32 matrix (dtype C2_BF16X3P)."""
+    [2, rows, cols] (hi, lo) that split_bf16 makes of an fp32 matrix (dtype C2_BF16X3P).  The planes may be a view into
+    padded storage (row pitch and plane stride of their own: the launch then names both planes by pointer)."""
     if t.dim() == 3:
-        if t.dtype != torch.bfloat16 or t.shape[0] != 2 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
-            raise L.C2Error(f"{name}: planes must be a [2, rows, cols] bf16 tensor with plane stride rows*ld")
+        if t.dtype != torch.bfloat16 or t.shape[0] != 2 or (t.stride(2) != 1 and t.shape[2] > 1):
+            raise L.C2Error(f"{name}: planes must be a [2, rows, cols] bf16 tensor with unit inner stride")
         return tuple(t.shape[1:]), t.stride(1), L.BF16X3P
     return tuple(t.shape), _row_major(t, name), _gemm_code(t.dtype, x3)
 
 
+def _lo(t):
+    """Pointer to the low plane of a planes operand."""
+    return t.data_ptr() + t.stride(0) * 2
+
+
 def split_bf16(src, out=None):
-    """fp32 [rows, cols] -> bf16 planes [2, rows, cols]: hi = bf16(x), lo = bf16(x - hi)."""
+    """fp32 [rows, cols] -> bf16 planes [2, rows, cols]: hi = bf16(x), lo = bf16(x - hi).  `out` may be a view into padded
+    storage (row pitch >= cols, any plane stride)."""
     L.require_gpu(src)
     rows, cols = src.shape
     assert src.dtype == torch.float32
     if out is None:
         out = torch.empty((2, rows, cols), dtype=torch.bfloat16, device=src.device)
-    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (2, rows, cols) and out.is_contiguous()
-    check(lib.c2_split_bf16(ptr(src), rows, cols, _row_major(src, "src"), ptr(out), cols, stream()))
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (2, rows, cols) and (out.stride(2) == 1 or cols <= 1)
+    check(lib.c2_split_bf16_planes(ptr(src), rows, cols, _row_major(src, "src"), ptr(out), _lo(out), out.stride(1), stream()))
     return out
 
 
@@ -86,6 +93,8 @@ def planes_ok(M, N, R, lds=()):
 def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False):
     """Number of slabs a reduction of length R is split into for an [M,N] output, so that the launch fills the
     256 CUs: >= ~2 blocks per CU of the register-staged 128x128 kernel, one block per CU of the LDS-DMA kernels."""
+    if planes:
+        R = (R + 7) // 8 * 8  # (planes of a width that is not a multiple of 8 are reduced over their zero-padded length)
     tile = gemm_tile(dtype, M, N, R, x3, planes)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     bk = 64 if (planes or dtype != torch.float32) else 32
@@ -176,8 +185,12 @@ def linear_fwd(a, w, y, bias=None, nslab=1, x3=False):
     ss = y.stride(0) if y.dim() == 3 else 0
     assert (y.dim() == 3 and y.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_fwd(ptr(a), lda, ptr(w), ldw, code, M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss,
-                                ptr(bias), stream()))
+        if code == L.BF16X3P:
+            check(lib.c2_linear_fwd_planes(ptr(a), _lo(a), lda, ptr(w), _lo(w), ldw, M, N, K, ptr(y), _row_major(y2, "y"),
+                                           nslab, ss, ptr(bias), stream()))
+        else:
+            check(lib.c2_linear_fwd(ptr(a), lda, ptr(w), ldw, code, M, N, K, ptr(y), _row_major(y2, "y"), nslab, ss,
+                                    ptr(bias), stream()))
     return y
 
 
@@ -288,8 +301,12 @@ def linear_dgrad(dy, w, da, nslab=1, alpha=None, x3=False):
     ss = da.stride(0) if da.dim() == 3 else 0
     assert (da.dim() == 3 and da.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_dgrad(ptr(dy), lddy, ptr(w), ldw, code, M, N, K, ptr(da), _row_major(d2, "da"), nslab, ss,
-                                  ptr(alpha), stream()))
+        if code == L.BF16X3P:
+            check(lib.c2_linear_dgrad_planes(ptr(dy), _lo(dy), lddy, ptr(w), _lo(w), ldw, M, N, K, ptr(da),
+                                             _row_major(d2, "da"), nslab, ss, ptr(alpha), stream()))
+        else:
+            check(lib.c2_linear_dgrad(ptr(dy), lddy, ptr(w), ldw, code, M, N, K, ptr(da), _row_major(d2, "da"), nslab, ss,
+                                      ptr(alpha), stream()))
     return da
 
 
@@ -304,8 +321,12 @@ def linear_wgrad(dy, a, dw, nslab=1, alpha=None, x3=False, rank1=None):
     ss = dw.stride(0) if dw.dim() == 3 else 0
     assert (dw.dim() == 3 and dw.shape[0] == nslab) or nslab == 1
     with _GemmTimer(M, N, K):
-        check(lib.c2_linear_wgrad(ptr(dy), lddy, ptr(a), lda, code, M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
-                                  ptr(alpha), *_rank1(rank1, N, K), stream()))
+        if code == L.BF16X3P:
+            check(lib.c2_linear_wgrad_planes(ptr(dy), _lo(dy), lddy, ptr(a), _lo(a), lda, M, N, K, ptr(dw),
+                                             _row_major(d2, "dw"), nslab, ss, ptr(alpha), *_rank1(rank1, N, K), stream()))
+        else:
+            check(lib.c2_linear_wgrad(ptr(dy), lddy, ptr(a), lda, code, M, N, K, ptr(dw), _row_major(d2, "dw"), nslab, ss,
+                                      ptr(alpha), *_rank1(rank1, N, K), stream()))
     return dw
 
 

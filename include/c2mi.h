@@ -143,6 +143,23 @@ int c2_gemm_tile(int dtype, int64_t M, int64_t N, int64_t R);
  * most 2^21 multiply-adds): a caller that would split such operands into bf16 planes (C2_BF16X3P) should not. */
 int c2_gemm_is_tiny(int64_t M, int64_t N, int64_t R);
 
+/* The three Linear GEMMs on C2_BF16X3P operands whose two planes are given by TWO POINTERS each (hi, lo) instead of one
+ * pointer and the convention "lo follows hi after rows x ld elements": operands whose planes live in padded storage -- a
+ * width that is not a multiple of 8 (the reference's hidden width 820, latent widths 26 / 10) gets a row pitch rounded up
+ * to 8 and zero pad columns, a weight that is also reduced over its rows (the input gradient) zero pad ROWS, and the
+ * reduction then runs over the padded length, adding exact zeros.  Same kernels and arguments as c2_linear_fwd /
+ * c2_linear_dgrad / c2_linear_wgrad with dtype C2_BF16X3P otherwise (no counterpart in the reference). */
+int c2_linear_fwd_planes(const void* A_hi, const void* A_lo, int64_t lda, const void* W_hi, const void* W_lo, int64_t ldw,
+                         int64_t M, int64_t N, int64_t K, float* Y, int64_t ldy, int nslab, int64_t slab_stride,
+                         const float* bias, void* stream);
+int c2_linear_dgrad_planes(const void* dY_hi, const void* dY_lo, int64_t lddy, const void* W_hi, const void* W_lo,
+                           int64_t ldw, int64_t M, int64_t N, int64_t K, float* dA, int64_t ldda, int nslab,
+                           int64_t slab_stride, const float* alpha_dev, void* stream);
+int c2_linear_wgrad_planes(const void* dY_hi, const void* dY_lo, int64_t lddy, const void* A_hi, const void* A_lo,
+                           int64_t lda, int64_t M, int64_t N, int64_t K, float* dW, int64_t lddw, int nslab,
+                           int64_t slab_stride, const float* alpha_dev, const float* rank1_row, const float* rank1_col,
+                           void* stream);
+
 /* Input gradient and weight gradient of ONE tiny fp32 layer in one launch (no counterpart in the reference, whose autograd
  * launches the two GEMMs of nn.Linear's backward, modules.py:77-107, separately):  dA[M,K] = alpha * dY[M,N] W[N,K] and
  * dW[N,K] = alpha * dY^T A[M,K], alpha = *alpha_dev (1 when NULL).  Both problems must pass c2_gemm_is_tiny; same
@@ -154,6 +171,9 @@ int c2_linear_bwd_tiny(const float* dY, int64_t lddy, const float* W, int64_t ld
 /* fp32 [rows, cols] -> two bf16 planes dst[0] = hi = bf16(x), dst[1] = lo = bf16(x - hi); dst is [2][rows][ldd].
  * Producer side of C2_BF16X3P (no counterpart in the reference, which multiplies in fp32). */
 int c2_split_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t ldd, void* stream);
+/* ... with the two planes at addresses of their own (padded storage, see c2_linear_fwd_planes): [rows][ldd] each. */
+int c2_split_bf16_planes(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_hi, void* dst_lo, int64_t ldd,
+                         void* stream);
 
 /* out[i] = sum_s slabs[s][i] (fp32), n elements: closes a split wgrad. */
 int c2_sum_slabs(const float* slabs, int nslab, int64_t slab_stride, float* out, int64_t n, void* stream);
