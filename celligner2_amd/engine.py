@@ -434,7 +434,10 @@ class StepEngine:
     # as three bf16 products by the LDS-DMA kernel (C2_BF16X3P); shapes it cannot take stay on the in-kernel split.
     @staticmethod
     def _r8(n):
-        return (int(n) + 7) // 8 * 8
+        """Padded length of a plane operand's rows (and of a weight's row count): the next multiple of 8, and at least the 64
+        of one K-tile -- the LDS-DMA kernels take reductions of 64 and more, and a shorter one (the reference's latent
+        widths 26 / 10, a 30-way classifier) runs over its zero pad like any other padded length."""
+        return max(64, (int(n) + 7) // 8 * 8)
 
     def _planes_of(self, t):
         """(hi, lo) bf16 planes of this step's fp32 matrix t [rows, cols].  A width that is not a multiple of 8 gets planes
@@ -454,8 +457,8 @@ class StepEngine:
         """bf16x3 mode: planes buffer that the layer-tail kernel fills together with its fp32 output `t` (registered
         as t's planes for this step), or None when t is not an fp32 operand of a narrow GEMM / shape not vectorisable."""
         B, H = t.shape
-        if not (self.x3 and t.dtype == F32 and t.is_contiguous() and H % 8 == 0 and H <= 1024 and (B * H) % 4 == 0):
-            return None
+        if not (self.x3 and t.dtype == F32 and t.is_contiguous() and self._r8(H) == H and H <= 1024 and (B * H) % 4 == 0):
+            return None  # (other widths: _planes_of splits into padded storage when a GEMM asks)
         pl = self.buf(key, (2, B, H), torch.bfloat16)
         self._aplanes[(t.data_ptr(), (B, H))] = pl
         return pl
@@ -495,7 +498,7 @@ class StepEngine:
         if not self.x3 or ops.gemm_is_tiny(M, N, R):
             return 0
         if mode == "wgrad":
-            if R % 8:
+            if R % 8 or R < 64:
                 return 0
             R8, lds = R, (r8(M), r8(N))
         else:
@@ -518,6 +521,7 @@ class StepEngine:
         if R8 != R:
             cols = lambda pl: pl.as_strided((2, pl.shape[1], R8), pl.stride(), pl.storage_offset())  # noqa: E731
             rows = lambda pl: pl.as_strided((2, R8, pl.shape[2]), pl.stride(), pl.storage_offset())  # noqa: E731
+            assert px.stride(1) >= R8 and (py.stride(1) >= R8 if mode == "fwd" else py.stride(0) >= R8 * py.stride(1))
             px = cols(px)
             py = cols(py) if mode == "fwd" else rows(py)
         return px, py, True

@@ -94,7 +94,7 @@ def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False
     """Number of slabs a reduction of length R is split into for an [M,N] output, so that the launch fills the
     256 CUs: >= ~2 blocks per CU of the register-staged 128x128 kernel, one block per CU of the LDS-DMA kernels."""
     if planes:
-        R = (R + 7) // 8 * 8  # (planes of a width that is not a multiple of 8 are reduced over their zero-padded length)
+        R = max(64, (R + 7) // 8 * 8)  # (planes are reduced over their zero-padded length: a multiple of 8, one K-tile at least)
     tile = gemm_tile(dtype, M, N, R, x3, planes)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     bk = 64 if (planes or dtype != torch.float32) else 32
