@@ -34,7 +34,8 @@ class SlabSum(C.Structure):
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp), ("shadow_f16", i32)]
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", i64), ("shadow_lo", vp), ("shadow_f16", i32),
+                ("shadow_cols", i32), ("shadow_ld", i64)]
 
 
 _SIGS = {
@@ -60,8 +61,8 @@ _SIGS = {
     "c2_sum_slabs_2d": (i32, [vp, i32, i64, i64, i64, i64, vp, i64, vp]),
     "c2_sum_slabs": (i32, [vp, i32, i64, vp, i64, vp]),
     "c2_sum_slabs_multi": (i32, [C.POINTER(SlabSum), i32, vp]),
-    "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp, vp]),
-    "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp, vp]),
+    "c2_epilogue_fwd": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, vp, f32, i32, i64, i64, vp, i32, i64, vp, vp, vp, i64, vp]),
+    "c2_epilogue_bwd": (i32, [vp, i64, i32, i64, vp, i64, vp, vp, f32, i32, vp, vp, i64, i64, vp, i32, i64, vp, i64, vp]),
     "c2_bn_ws": (sz, [i64, i64]),
     "c2_bn_stats": (i32, [vp, i64, i32, i64, vp, vp, i32, vp, i64, i64, i64, vp, vp, vp, vp]),
     "c2_bn_fwd": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, f32, i32, f32, vp, f32, i64, i64, vp, i32, i64, vp,

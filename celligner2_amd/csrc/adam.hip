@@ -30,8 +30,16 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 // operand copies the GEMMs read: bf16(p), and bf16(p - bf16(p)) for the narrow layers' planes
+__device__ __forceinline__ int64_t shadow_index(const c2_adam_tensor& t, int64_t i) {
+    if (t.shadow_cols == 0) return i;
+    // (rows shadow_ld apart: planes in padded storage.  32-bit division where the index allows: the 64-bit one costs more
+    // than the rest of the update of a chunk)
+    const int64_t r = i < (1ll << 32) ? (int64_t)((unsigned)i / (unsigned)t.shadow_cols) : i / t.shadow_cols;
+    return r * t.shadow_ld + (i - r * t.shadow_cols);
+}
 __device__ __forceinline__ void store_shadows(const c2_adam_tensor& t, int64_t i, const f32x4& p) {
     u32x2 pk;
+    i = shadow_index(t, i);  // (a chunk of four never straddles rows: shadow_cols % 4 == 0)
     if (t.shadow_f16) {  // an IEEE-half copy (the encoder's first layer in bf16 mode): no low plane
         pk[0] = pack2<f16_t>(p[0], p[1]);
         pk[1] = pack2<f16_t>(p[2], p[3]);
@@ -152,12 +160,13 @@ __device__ __forceinline__ void adam_block(const AdamTable& tab, const AdamHyper
                 float pe = t.p[i + e], me = t.m[i + e], ve = t.v[i + e];
                 adam_one(pe, t.g[i + e], me, ve, h);
                 t.p[i + e] = pe; t.m[i + e] = me; t.v[i + e] = ve;
+                const int64_t si = t.shadow_bf16 ? shadow_index(t, i + e) : 0;
                 if (t.shadow_bf16 && t.shadow_f16) {
-                    reinterpret_cast<f16_t*>(t.shadow_bf16)[i + e] = (f16_t)pe;
+                    reinterpret_cast<f16_t*>(t.shadow_bf16)[si] = (f16_t)pe;
                 } else if (t.shadow_bf16) {
                     const bf16_t hb = f2bf(pe);
-                    reinterpret_cast<bf16_t*>(t.shadow_bf16)[i + e] = hb;
-                    if (t.shadow_lo) reinterpret_cast<bf16_t*>(t.shadow_lo)[i + e] = f2bf(pe - bf2f(hb));
+                    reinterpret_cast<bf16_t*>(t.shadow_bf16)[si] = hb;
+                    if (t.shadow_lo) reinterpret_cast<bf16_t*>(t.shadow_lo)[si] = f2bf(pe - bf2f(hb));
                 }
             }
         }
@@ -180,6 +189,9 @@ static int adam_launch(const c2_adam_tensor* desc_host, int n_tensors, const Ada
             if (d.n == 0) continue;
             C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");
             C2_CHECK(!d.shadow_lo || d.shadow_bf16, "shadow_lo without the high plane");
+            C2_CHECK(d.shadow_cols == 0 || (d.shadow_cols > 0 && d.shadow_cols % 4 == 0 && d.shadow_ld >= d.shadow_cols &&
+                                            d.shadow_ld % 4 == 0 && d.n % d.shadow_cols == 0),
+                     "pitched shadows need shadow_cols % 4 == 0, shadow_ld % 4 == 0 >= shadow_cols, n a whole number of rows");
             C2_CHECK(!(d.shadow_f16 && d.shadow_lo), "an f16 shadow has no low plane");
             tab.t[tab.n] = d;
             tab.first_block[tab.n] = blocks;

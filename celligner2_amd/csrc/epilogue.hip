@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
     const float* __restrict__ Y, int64_t ldy, int nslab, int64_t slab_stride, const float* __restrict__ bias,
     const int64_t* __restrict__ cond, int C, const float* __restrict__ Wc, int64_t ldwc,
     const uint8_t* __restrict__ mask, float keep_scale, int use_ln, int64_t B, int H, TO* __restrict__ act,
-    int64_t ldact, float* __restrict__ yhat, float* __restrict__ rstd_out, bf16_t* __restrict__ planes) {
+    int64_t ldact, float* __restrict__ yhat, float* __restrict__ rstd_out, bf16_t* __restrict__ planes, int64_t ldp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
         rstd = 1.0f / sqrtf(var + 1e-5f);
     }
     if (rstd_out && lane == 0) rstd_out[row] = rstd;
-    const int64_t plane = B * (int64_t)H;
+    const int64_t plane = B * ldp;  // (planes: rows ldp elements apart, the low plane B rows on)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
                 for (int e = 0; e < 4; ++e) r[e] = ((mb >> (8 * e)) & 0xffu) ? r[e] * keep_scale : 0.f;
             }
             store_out4(act + row * ldact + c, r);
-            if (planes) store_planes4(planes + row * (int64_t)H + c, plane, r);
+            if (planes) store_planes4(planes + row * ldp + c, plane, r);
         }
     }
 }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
     const float* __restrict__ dA, int64_t ldda, int nslab, int64_t slab_stride, const float* __restrict__ extra,
     int64_t ldextra, const float* __restrict__ extra_scale_dev, const uint8_t* __restrict__ mask, float keep_scale,
     int use_ln, const float* __restrict__ yhat, const float* __restrict__ rstd_in, int64_t B, int H,
-    TO* __restrict__ dh, int64_t lddh, bf16_t* __restrict__ planes) {
+    TO* __restrict__ dh, int64_t lddh, bf16_t* __restrict__ planes, int64_t ldp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
         m2 = wave_sum(s2) / (float)H;
         rstd = rstd_in[row];
     }
-    const int64_t plane = B * (int64_t)H;
+    const int64_t plane = B * ldp;  // (planes: rows ldp elements apart, the low plane B rows on)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = use_ln ? (cdy[i][e] - m1 - cyh[i][e] * m2) * rstd : cdy[i][e];
             store_out4(dh + row * lddh + c, g);
-            if (planes) store_planes4(planes + row * (int64_t)H + c, plane, g);
+            if (planes) store_planes4(planes + row * ldp + c, plane, g);
         }
     }
 }
@@ -1161,8 +1161,10 @@ extern "C" int c2_prep_input(const float* x, int64_t rows, int64_t cols, int64_t
 extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                                const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
                                float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype,
-                               int64_t ldact, float* yhat, float* rstd, void* act_planes, void* stream) {
+                               int64_t ldact, float* yhat, float* rstd, void* act_planes, int64_t ld_planes, void* stream) {
     C2_CHECK(Y && act, "null pointer");
+    const int64_t ldp = ld_planes ? ld_planes : H;
+    C2_CHECK(!act_planes || ldp >= H, "ld_planes shorter than a row");
     C2_CHECK(!act_planes || act_dtype == C2_F32, "planes accompany an fp32 activation");
     C2_CHECK(act_dtype == C2_F32 || act_dtype == C2_BF16, "bad dtype");
     C2_CHECK(nslab >= 1 && ldy >= H && ldact >= H && H < (1ll << 31), "bad shape");
@@ -1177,11 +1179,11 @@ extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t s
                      aligned16(Y) && (!bias || aligned16(bias)) && (!yhat || aligned16(yhat)) &&
                      ((reinterpret_cast<uintptr_t>(act) & (act_dtype == C2_F32 ? 15 : 7)) == 0) &&
                      (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
-                     (!act_planes || ((reinterpret_cast<uintptr_t>(act_planes) & 7) == 0 && (B * H) % 4 == 0));
+                     (!act_planes || ((reinterpret_cast<uintptr_t>(act_planes) & 7) == 0 && ldp % 4 == 0 && (B * ldp) % 4 == 0));
     C2_CHECK(vec || !act_planes, "act_planes needs the vector path (H % 4 == 0, H <= 1024, aligned rows)");
 #define LAUNCHV(TO, E)                                                                                                 \
     hipLaunchKernelGGL((epilogue_fwd_vec_kernel<TO, E>), grid, dim3(256), 0, st, Y, ldy, nslab, slab_stride, bias, cond, \
-                       C, Wc, ldwc, mask, ks, use_ln, B, (int)H, (TO*)act, ldact, yhat, rstd, (bf16_t*)act_planes)
+                       C, Wc, ldwc, mask, ks, use_ln, B, (int)H, (TO*)act, ldact, yhat, rstd, (bf16_t*)act_planes, ldp)
     if (vec) {
         if (act_dtype == C2_F32) {
             if (H <= 256) LAUNCHV(float, 1); else if (H <= 512) LAUNCHV(float, 2); else LAUNCHV(float, 4);
@@ -1208,8 +1210,10 @@ extern "C" int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t s
 extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
                                int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
                                int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
-                               int dh_dtype, int64_t lddh, void* dh_planes, void* stream) {
+                               int dh_dtype, int64_t lddh, void* dh_planes, int64_t ld_planes, void* stream) {
     C2_CHECK(dA && yhat && dh, "null pointer");
+    const int64_t ldp = ld_planes ? ld_planes : H;
+    C2_CHECK(!dh_planes || ldp >= H, "ld_planes shorter than a row");
     C2_CHECK(!dh_planes || dh_dtype == C2_F32, "planes accompany an fp32 gradient");
     C2_CHECK(!use_ln || rstd, "rstd needed with use_ln");
     C2_CHECK(dh_dtype == C2_F32 || dh_dtype == C2_BF16, "bad dtype");
@@ -1223,12 +1227,12 @@ extern "C" int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t
                      aligned16(dA) && aligned16(yhat) && (!extra || (aligned16(extra) && ldextra % 4 == 0)) &&
                      ((reinterpret_cast<uintptr_t>(dh) & (dh_dtype == C2_F32 ? 15 : 7)) == 0) &&
                      (!mask || (reinterpret_cast<uintptr_t>(mask) & 3) == 0) &&
-                     (!dh_planes || ((reinterpret_cast<uintptr_t>(dh_planes) & 7) == 0 && (B * H) % 4 == 0));
+                     (!dh_planes || ((reinterpret_cast<uintptr_t>(dh_planes) & 7) == 0 && ldp % 4 == 0 && (B * ldp) % 4 == 0));
     C2_CHECK(vec || !dh_planes, "dh_planes needs the vector path (H % 4 == 0, H <= 1024, aligned rows)");
 #define LAUNCHV(TO, E)                                                                                               \
     hipLaunchKernelGGL((epilogue_bwd_vec_kernel<TO, E>), grid, dim3(256), 0, st, dA, ldda, nslab, slab_stride, extra, \
                        ldextra, extra_scale_dev, mask, ks, use_ln, yhat, rstd, B, (int)H, (TO*)dh, lddh,            \
-                       (bf16_t*)dh_planes)
+                       (bf16_t*)dh_planes, ldp)
     if (vec) {
         if (dh_dtype == C2_F32) {
             if (H <= 256) LAUNCHV(float, 1); else if (H <= 512) LAUNCHV(float, 2); else LAUNCHV(float, 4);

@@ -343,18 +343,32 @@ class StepEngine:
             return None
         sh = self._shadow.get(name)
         if sh is not None:
-            return sh if sh.is_contiguous() else None  # (a padded copy is refreshed by weight(), see there)
+            # (a copy in padded storage: the kernel maps its flat index through the row pitch when the width is a multiple
+            # of 4; else weight() converts again when the version has moved)
+            if sh.is_contiguous() or (sh.dim() == 2 and sh.shape[1] % 4 == 0 and sh.stride(0) % 4 == 0 and sh.stride(1) == 1):
+                return sh
+            return None
         # (planes in padded storage -- a width that is not a multiple of 8 -- are not dense: the kernel's flat indexing
         # does not apply, the engine splits such a weight again when its version has moved)
         c = self._wplanes.get(name)
         if c is not None:
-            return c[1] if c[1].is_contiguous() else None
+            return self._adam_planes(c[1][0], c[1][1])
         if name in (self.HEADS[0] + ".weight", self.HEADS[1] + ".weight"):
             c = self._wplanes.get(self.HEADW)  # rows [0,L) / [L,2L) of the stacked planes: (hi, lo) of this head
-            if c is not None and c[1].is_contiguous():
+            if c is not None:
                 L = self.p[name].shape[0]
                 k = 0 if name.startswith(self.HEADS[0]) else 1
-                return (c[1][0, k * L:(k + 1) * L], c[1][1, k * L:(k + 1) * L])
+                return self._adam_planes(c[1][0, k * L:(k + 1) * L], c[1][1, k * L:(k + 1) * L])
+        return None
+
+    @staticmethod
+    def _adam_planes(hi, lo):
+        """(hi, lo) as the fused Adam kernel takes them: dense planes, or rows a pitch apart when the width is a multiple of 4
+        (planes in padded storage); None otherwise -- the engine then splits the weight again when its version has moved."""
+        if hi.is_contiguous() and lo.is_contiguous():
+            return (hi, lo)
+        if hi.shape[1] % 4 == 0 and hi.stride(0) % 4 == 0 and hi.stride(1) == 1 and lo.stride() == hi.stride():
+            return (hi, lo)
         return None
 
     def copies_current(self, name):
@@ -453,13 +467,19 @@ class StepEngine:
             self._aplanes[key] = pl
         return pl
 
-    def _tail_planes(self, key, t):
+    def _tail_planes(self, key, t, pitched=True):
         """bf16x3 mode: planes buffer that the layer-tail kernel fills together with its fp32 output `t` (registered
-        as t's planes for this step), or None when t is not an fp32 operand of a narrow GEMM / shape not vectorisable."""
+        as t's planes for this step), or None when t is not an fp32 operand of a narrow GEMM / shape not vectorisable.
+        A width that is not a multiple of 8 (or below 64) gets the [2, B, H] view of zero-padded storage, as _planes_of
+        makes (pitched=False: dense planes or none -- the BatchNorm tails)."""
         B, H = t.shape
-        if not (self.x3 and t.dtype == F32 and t.is_contiguous() and self._r8(H) == H and H <= 1024 and (B * H) % 4 == 0):
-            return None  # (other widths: _planes_of splits into padded storage when a GEMM asks)
-        pl = self.buf(key, (2, B, H), torch.bfloat16)
+        if not (self.x3 and t.dtype == F32 and t.is_contiguous() and H % 4 == 0 and H <= 1024 and (B * H) % 4 == 0):
+            return None  # (_planes_of splits into padded storage when a GEMM asks)
+        c8 = self._r8(H)
+        if c8 != H and not pitched:
+            return None
+        full = self.buf(key, (2, B, c8), torch.bfloat16, zero=c8 != H)
+        pl = full[:, :, :H] if c8 != H else full
         self._aplanes[(t.data_ptr(), (B, H))] = pl
         return pl
 
@@ -747,7 +767,7 @@ class StepEngine:
         rstd = self.buf(blk.name + ".rstd", (B,)) if save else None
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if (train and p > 0) else None
-        planes = self._tail_planes(blk.name + ".act.pl", act)
+        planes = self._tail_planes(blk.name + ".act.pl", act, pitched=not blk.norm)
         bias = self.p[blk.b].detach() if blk.b else None
         if blk is self.enc[0] and self._center is not None:
             bias = self._ws["enc0.bias_eff"]
@@ -808,7 +828,7 @@ class StepEngine:
         p = self.cfg["dr_rate"]
         mask = masks.get(blk.drop_name) if p > 0 else None
         dh = self.abuf(blk.name + ".dh", (B, H), blk.gt)
-        planes = self._tail_planes(blk.name + ".dh.pl", dh)
+        planes = self._tail_planes(blk.name + ".dh.pl", dh, pitched=not blk.norm)
         if blk.norm:
             self._bn_bwd(blk, dact, mask, p if mask is not None else 0.0, dh, planes, extra, extra_scale)
         else:

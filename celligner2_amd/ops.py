@@ -386,6 +386,17 @@ def _planes_arg(planes, B, H):
     return ptr(planes)
 
 
+def _planes_ld(planes, B, H):
+    """(pointer, row pitch) of the planes a layer tail writes: dense [2, B, H], or a [2, B, H] view of padded storage whose
+    low plane lies B x pitch elements behind the high one."""
+    if planes is None:
+        return None, 0
+    assert planes.dtype == torch.bfloat16 and tuple(planes.shape) == (2, B, H) and (planes.stride(2) == 1 or H <= 1)
+    ld = planes.stride(1)
+    assert planes.stride(0) == B * ld, "the low plane must follow the high plane's B rows"
+    return ptr(planes), ld
+
+
 def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=None, planes=None):
     L.require_gpu(y, act)
     yt, ldy, ns, ss, B, H = _slabs(y)
@@ -402,7 +413,7 @@ def epilogue_fwd(y, bias, cond, wc, mask, p_drop, use_ln, act, yhat=None, rstd=N
     check(lib.c2_epilogue_fwd(ptr(yt), ldy, ns, ss, ptr(bias), ptr(cond) if C else None, C, ptr(wc) if C else None,
                               wc.stride(0) if C else 0, ptr(mask), float(p_drop), int(use_ln), B, H, ptr(act),
                               dt_code(act.dtype), _row_major(act, "act"), ptr(yhat), ptr(rstd),
-                              _planes_arg(planes, B, H), stream()))
+                              *_planes_ld(planes, B, H), stream()))
     return act
 
 
@@ -414,7 +425,7 @@ def epilogue_bwd(da, mask, p_drop, use_ln, yhat, rstd, dh, extra=None, extra_sca
         assert extra.dtype == torch.float32 and tuple(extra.shape) == (B, H)
     check(lib.c2_epilogue_bwd(ptr(dt), ldda, ns, ss, ptr(extra), extra.stride(0) if extra is not None else 0,
                               ptr(extra_scale), ptr(mask), float(p_drop), int(use_ln), ptr(yhat), ptr(rstd), B, H,
-                              ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), _planes_arg(planes, B, H), stream()))
+                              ptr(dh), dt_code(dh.dtype), _row_major(dh, "dh"), *_planes_ld(planes, B, H), stream()))
     return dh
 
 
@@ -683,19 +694,27 @@ def _adam_table(entries):
         assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
         assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and g.numel() == p.numel()
         lo = None
-        if isinstance(sh, tuple):  # (hi, lo) planes given separately (rows of a stacked operand)
+        cols = ld = 0
+        if isinstance(sh, tuple):  # (hi, lo) planes given separately (rows of a stacked operand, planes in padded storage)
             sh, lo = sh
-            assert lo.dtype == torch.bfloat16 and lo.is_contiguous() and lo.numel() == p.numel()
+            assert lo.dtype == torch.bfloat16 and lo.numel() == p.numel()
         f16 = 0
-        if sh is not None and sh.dtype == torch.float16:  # an IEEE-half operand copy (the encoder's first layer)
-            assert lo is None and sh.is_contiguous() and sh.numel() == p.numel()
-            f16 = 1
-        elif sh is not None:
-            assert sh.dtype == torch.bfloat16 and sh.is_contiguous()
-            if lo is None and sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
-                sh, lo = sh[0], sh[1]
+        if sh is not None:
+            if sh.dtype == torch.float16:  # an IEEE-half operand copy (the encoder's first layer)
+                assert lo is None
+                f16 = 1
+            else:
+                assert sh.dtype == torch.bfloat16
+                if lo is None and sh.numel() == 2 * p.numel() and sh.shape[0] == 2:
+                    sh, lo = sh[0], sh[1]
             assert sh.numel() == p.numel()
-        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo), f16)
+            if not sh.is_contiguous():  # rows a pitch apart (zero-padded storage): the kernel maps its flat index
+                assert sh.dim() == 2 and sh.stride(1) == 1 and sh.shape[1] % 4 == 0 and sh.stride(0) % 4 == 0
+                assert lo is None or (lo.shape == sh.shape and lo.stride() == sh.stride())
+                cols, ld = sh.shape[1], sh.stride(0)
+            else:
+                assert lo is None or lo.is_contiguous()
+        arr[i] = L.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel(), ptr(lo), f16, cols, ld)
     return arr, n
 
 

@@ -199,18 +199,20 @@ int c2_sum_slabs_2d(const float* slabs, int nslab, int64_t slab_stride, int64_t 
  * Writes act (dtype act_dtype) and, for the backward, yhat (fp32, normalised pre-activation) and
  * rstd (fp32 [B]).  cond is the int64 multi-hot matrix [B,C] (row stride C).
  * act_planes: NULL, or (fp32 act only) [2][B][H] bf16: the activation again as hi / lo planes, the operand form
- * of C2_BF16X3P GEMMs (saves a c2_split_bf16 pass); needs H % 4 == 0, H <= 1024 and 16-byte aligned rows. */
+ * of C2_BF16X3P GEMMs (saves a c2_split_bf16 pass); needs H % 4 == 0, H <= 1024 and 16-byte aligned rows.
+ * ld_planes: row pitch of the planes in elements (0: H), the low plane B x ld_planes elements behind the high one --
+ * planes in zero-padded storage for widths that are not multiples of 8 (c2_linear_fwd_planes); % 4 == 0. */
 int c2_epilogue_fwd(const float* Y, int64_t ldy, int nslab, int64_t slab_stride, const float* bias,
                     const int64_t* cond, int C, const float* Wc, int64_t ldwc, const uint8_t* mask,
                     float p_drop, int use_ln, int64_t B, int64_t H, void* act, int act_dtype, int64_t ldact,
-                    float* yhat, float* rstd, void* act_planes, void* stream);
+                    float* yhat, float* rstd, void* act_planes, int64_t ld_planes, void* stream);
 
 /* Backward of the same tail:  dact = sum_s dA[s] (+ extra_scale * extra); through dropout, ReLU, LayerNorm.
  * Writes dh (dtype dh_dtype), the gradient w.r.t. the Linear output; dh_planes as act_planes above. */
 int c2_epilogue_bwd(const float* dA, int64_t ldda, int nslab, int64_t slab_stride, const float* extra,
                     int64_t ldextra, const float* extra_scale_dev, const uint8_t* mask, float p_drop,
                     int use_ln, const float* yhat, const float* rstd, int64_t B, int64_t H, void* dh,
-                    int dh_dtype, int64_t lddh, void* dh_planes, void* stream);
+                    int dh_dtype, int64_t lddh, void* dh_planes, int64_t ld_planes, void* stream);
 
 /* Bias / condition-weight gradients of a block (autograd of modules.py:100-106):
  *   db[h] = alpha * sum_b dh[b][h];   dWc[h][j] = alpha * sum_b dh[b][h] * cond[b][j]
@@ -355,6 +357,8 @@ typedef struct {
     void* shadow_lo;   /* NULL, or [n] bf16: the low plane lo = bf16(p - hi) next to shadow_bf16 = hi = bf16(p), the
                           C2_BF16X3P operand form of the fp32 weights of the narrow layers */
     int32_t shadow_f16; /* non-zero: shadow_bf16 addresses [n] IEEE halves (C2_F16) instead of bf16; no shadow_lo */
+    int32_t shadow_cols; /* 0: the shadows are dense [n]; else the parameter is a matrix with this many columns (% 4 == 0) */
+    int64_t shadow_ld;   /* and its shadows have rows shadow_ld elements apart (planes in zero-padded storage) */
 } c2_adam_tensor;
 int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
                  double weight_decay, double clip_value, int64_t step_t, void* stream);
