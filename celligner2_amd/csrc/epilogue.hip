@@ -1293,12 +1293,15 @@ extern "C" int c2_bias_cond_grad(const void* dh, int dh_dtype, int64_t lddh, con
         return 0;
     }
     const int W = dh_dtype == C2_F32 ? 4 : 8;
-    const bool vecp = H % W == 0 && lddh % W == 0 && aligned16(dh) && H >= 64 * W;
+    // (a width that is not a multiple of W with rows that are: the last chunk of a row reads into the row's pad, whose sums
+    // are not written -- the 2-byte activations of widths like 820 have rows padded to 8 elements)
+    const int64_t HW = (H + W - 1) / W * W;
+    const bool vecp = lddh % W == 0 && lddh >= HW && aligned16(dh) && H >= 64 * W;
     // rows per chunk: 32 for the narrow matrices (more workgroups than 128-row chunks give), 128 otherwise / scalar path
     const int rb = (vecp && H * (int64_t)((B + 127) / 128) < 256ll * 64 * W) ? 32 : kBCG_RB;
     const int nchunk = (int)std::max<int64_t>(1, (B + rb - 1) / rb);
     if (vecp) {
-        dim3 gv((unsigned)((H / W + 63) / 64), nchunk);
+        dim3 gv((unsigned)((HW / W + 63) / 64), nchunk);
 #define BCV_L(TI, CC, c0) \
     hipLaunchKernelGGL((bias_stage1_vec<TI, CC>), gv, dim3(256), 0, st, (const TI*)dh, lddh, cond, C, c0, B, (int)H, rb, ws)
         for (int c0 = 0; c0 == 0 || c0 < C; c0 += 4) {
