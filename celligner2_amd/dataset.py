@@ -217,7 +217,7 @@ class DeviceDataset:
         t = cache.get(key)
         if t is None:
             # (rows start on 16 bytes for the LDS-DMA GEMMs: a gene count that is not a multiple of 8 gets zero pad columns)
-            t = torch.zeros((self.n, (self.G + 7) // 8 * 8), dtype=dtype, device=self.device)[:, :self.G]
+            t = torch.zeros((self.n, ops.pitch2(self.G)), dtype=dtype, device=self.device)[:, :self.G]
             c = self.xin_center(apply_log) if centered else None
             for s in range(0, self.n, 16384):
                 ops.prep_input(self.data[s:s + 16384], t[s:s + 16384], bool(apply_log), c)
@@ -244,7 +244,7 @@ class DeviceDataset:
         center = self.xin_center(apply_log) if centered else None
         resident_rows = resident_rows and xin_dtype is not None
         resident_xin = (resident_xin and resident_rows and xin_dtype in (torch.bfloat16, torch.float16)
-                        and self.n * self.G < 2 ** 31 and n % 8 == 0)
+                        and self.n * ops.pitch2(self.G) < 2 ** 31 and n % 8 == 0)
         bufs = bufs if bufs is not None else {}
 
         def get(key, shape, dtype):
@@ -283,8 +283,8 @@ class DeviceDataset:
             idx32 = out["row_index32"] = get("row_index32", ((n + 63) // 64 * 64,), torch.int32)
         elif xin_dtype is not None:
             def two_byte_rows(key, dtype):
-                if self.G % 8:  # (see xin_resident)
-                    g8 = (self.G + 7) // 8 * 8
+                g8 = ops.pitch2(self.G)
+                if g8 != self.G:  # (see xin_resident)
                     full = bufs.get(key + ".padded")
                     if full is None or tuple(full.shape) != (n, g8) or full.dtype != dtype:
                         full = bufs[key + ".padded"] = torch.zeros((n, g8), dtype=dtype, device=self.device)

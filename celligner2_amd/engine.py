@@ -194,23 +194,22 @@ class StepEngine:
         return t
 
     def abuf(self, key, shape, dtype):
-        """A [B, H] activation that a gene-width GEMM may read as a bf16 operand.  The LDS-DMA kernels move 16-byte chunks
-        from 16-byte-aligned rows, so a 2-byte matrix whose width is not a multiple of 8 (the reference's own
-        hidden_layer_sizes=[820, 512, 256]) gets a leading dimension rounded up to 8 elements; the pad columns are zeroed
-        once, when the buffer is made, and never written again (the layer tails write H columns), so a reduction over
-        the padded width adds exact zeros.  Returns the [B, H] view."""
+        """A [B, H] activation that a gene-width GEMM may read as a 2-byte operand: rows ops.pitch2(H) elements apart (aligned
+        rows, whole K-tiles: see there), the pad columns zeroed once, when the buffer is made, and never written again (the
+        producers write H columns), so a reduction over the padded width adds exact zeros.  Returns the [B, H] view."""
         B, H = shape
-        if dtype == F32 or H % 8 == 0:
+        ld = ops.pitch2(H)
+        if dtype == F32 or ld == H:
             return self.buf(key, shape, dtype)
-        t = self.buf(key, (B, (H + 7) // 8 * 8), dtype, zero=True)
+        t = self.buf(key, (B, ld), dtype, zero=True)
         v = self._ws[key] = t[:, :H]
         return v
 
     @staticmethod
     def _padded_width(t):
-        """Row stride of a 2-byte [rows, cols] view made by abuf / weight() over a zero-padded buffer, else 0."""
-        if t.dim() == 2 and t.element_size() == 2 and t.shape[1] % 8 and t.stride(1) == 1 and \
-                t.stride(0) == (t.shape[1] + 7) // 8 * 8:
+        """Row stride of a 2-byte [rows, cols] view made by abuf / weight() / the dataset over a zero-padded buffer, else 0."""
+        if t.dim() == 2 and t.element_size() == 2 and t.stride(1) == 1 and t.stride(0) != t.shape[1] and \
+                t.stride(0) == ops.pitch2(t.shape[1]):
             return t.stride(0)
         return 0
 
@@ -314,15 +313,13 @@ class StepEngine:
         wdt = self.fwd16 if (self.fwd16 is not None and name == self.enc[0].w) else torch.bfloat16
         sh = self._shadow.get(name)
         if sh is None or sh.shape != p.shape:
-            if p.dim() == 2 and (p.shape[0] % 8 or p.shape[1] % 8):
-                # rows of a width that is not a multiple of 8 elements: leading dimension rounded up, pad zeroed once
-                # (see abuf); such a copy is converted here, after every optimizer step, not inside the Adam kernel
-                # (which addresses a contiguous copy): shadow_for_adam() does not hand it out.
-                # A row COUNT that is not a multiple of 8 (the output layer's [G, H] at a gene count like 19 004): zero
-                # rows up to the next multiple, so that the input gradient's reduction over the genes can run over the
-                # padded count (_dgrad); the [G, H] view stays contiguous and the Adam kernel keeps refreshing it.
-                r8, ldp = (p.shape[0] + 7) // 8 * 8, (p.shape[1] + 7) // 8 * 8
-                sh = torch.zeros((r8, ldp), dtype=wdt, device=self.dev)[:p.shape[0], :p.shape[1]]
+            rp, ldp = (ops.pitch2(p.shape[0]), ops.pitch2(p.shape[1])) if p.dim() == 2 else (0, 0)
+            if p.dim() == 2 and (rp != p.shape[0] or ldp != p.shape[1]):
+                # rows ops.pitch2(width) elements apart, pad zeroed once (see abuf), and zero ROWS up to pitch2(row count): the
+                # output layer's [G, H] is reduced over its rows by the input gradient, together with dlogits' padded columns
+                # (_dgrad).  The Adam kernel refreshes such a copy through its row pitch when the width is a multiple of 4
+                # (shadow_for_adam), else it is converted here after every optimizer step.
+                sh = torch.zeros((rp, ldp), dtype=wdt, device=self.dev)[:p.shape[0], :p.shape[1]]
             else:
                 sh = torch.empty(p.shape, dtype=wdt, device=self.dev)
             self._shadow[name] = sh
@@ -565,11 +562,11 @@ class StepEngine:
     def _dgrad(self, dy, wname, out_slabs, alpha=None):
         w = self.weight(wname)
         ld = self._padded_width(dy)
-        if ld and w.dtype == dy.dtype and w.shape[0] == dy.shape[1] and w.is_contiguous() and w.shape[1] % 8 == 0 \
-                and w.untyped_storage().nbytes() >= (w.storage_offset() + ld * w.shape[1]) * 2:
-            # reduction over a gene count that is not a multiple of 8: dy's pad columns and w's pad rows are zero
+        if ld and w.dtype == dy.dtype and w.shape[0] == dy.shape[1] and w.stride(1) == 1 and w.stride(0) % 8 == 0 \
+                and w.untyped_storage().nbytes() >= (w.storage_offset() + ld * w.stride(0)) * 2:
+            # reduction over the genes' padded count: dy's pad columns and w's pad rows are zero
             dy = dy.as_strided((dy.shape[0], ld), (ld, 1), dy.storage_offset())
-            w = w.as_strided((ld, w.shape[1]), (w.shape[1], 1), w.storage_offset())
+            w = w.as_strided((ld, w.shape[1]), (w.stride(0), 1), w.storage_offset())
         d2, w2, _ = self._pair(dy, w, dy.shape[0], w.shape[1], w.shape[0], wy=wname, mode="dgrad")
         ops.linear_dgrad(d2, w2, out_slabs, nslab=out_slabs.shape[0], alpha=alpha, x3=self.x3)
 
@@ -1055,7 +1052,7 @@ class StepEngine:
             logits4[:, G:].fill_(-float("inf"))
             logits = self._ws["logits"] = logits4[:, :G]
         elif half_logits:
-            logits = self.buf("logits16", (B, G), torch.float16)
+            logits = self.abuf("logits16", (B, G), torch.float16)  # (rows a padded pitch apart: aligned stores and loads)
             self._ws["logits"] = logits
         else:
             logits = self.buf("logits", (B, G))

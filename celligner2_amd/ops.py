@@ -38,6 +38,21 @@ def _gemm_code(dtype, x3):
     return L.F32X3 if (x3 and dtype == torch.float32) else dt_code(dtype)
 
 
+def pitch2(n):
+    """Row pitch (elements) of a 2-byte matrix with n columns that a gene-width GEMM reads: rows start on 256 bytes at gene
+    widths, on 128 bytes at hidden widths, on 16 below 64 columns.  The LDS-DMA kernels move a row's 128-byte K-tile slab per
+    eight lanes: from rows that start anywhere on 16 bytes (19 000 genes = 38 000 bytes apart) most slabs straddle two cache
+    lines, and a reduction length that is not a whole number of 64-element K-tiles ends in a tile staged through registers.
+    Measured on the C4 shapes (tools/dbg/gpitch.py, ktail.py): encoder forward 158.6 -> 136.8 us at a pitch of 19 072, the
+    output layer's input gradient 134.5 -> 126.8, its forward at hidden width 820 179.7 -> 138.1 us at a pitch of 832."""
+    n = int(n)
+    if n >= 2048:
+        return (n + 127) // 128 * 128
+    if n >= 64:
+        return (n + 63) // 64 * 64
+    return (n + 7) // 8 * 8
+
+
 def _row_major(t, name):
     if t.dim() != 2 or t.stride(1) != 1:
         raise L.C2Error(f"{name}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")

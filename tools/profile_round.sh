@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's profiles in one GPU call: kernel trace + stats of the bench command (C4 and C2, step replayed as a HIP
+# The round's profiles in one GPU call: kernel trace + stats of the bench command (C4, C2 and C3, step replayed as a HIP
 # graph), the HBM-traffic passes of the gene-width GEMMs, and the bench lines themselves.  Every GPU step has its own
 # time limit and the script stops at the first failure.  usage: tools/profile_round.sh <tag>   (GPU box only)
 set -o pipefail
@@ -9,7 +9,7 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for cfg in c4 c2; do
+for cfg in c4 c2 c3; do
   steps=20; warm=5
   [ $cfg = c2 ] && { steps=200; warm=20; }
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/trace_$cfg -- python3 $root/bench.py --profile-pass --config $cfg --steps $steps --warmup $warm > $out/trace_$cfg.log 2>&1 || exit 3
