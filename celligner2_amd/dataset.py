@@ -105,12 +105,12 @@ class DeviceDataset:
         return self.n
 
     def _pitched(self, src, dtype, chunk=16384):
-        """[n, G] view over a zero-initialised [n, G rounded up to 4] device matrix holding `src` (host or device tensor; None:
-        all ones), filled in row chunks (no second full-size temporary)."""
-        g4 = (self.G + 3) // 4 * 4
-        if src is not None and g4 == self.G:
+        """[n, G] view over a zero-initialised [n, ops.rows_pitch(G)] device matrix holding `src` (host or device tensor;
+        None: all ones), filled in row chunks (no second full-size temporary)."""
+        ld = ops.rows_pitch(self.G)
+        if src is not None and ld == self.G:
             return src.to(self.device, dtype).contiguous()
-        full = torch.zeros((self.n, g4), dtype=dtype, device=self.device)
+        full = torch.zeros((self.n, ld), dtype=dtype, device=self.device)
         view = full[:, :self.G]
         for s0 in range(0, self.n, chunk):
             if src is None:
@@ -118,6 +118,11 @@ class DeviceDataset:
             else:
                 view[s0:s0 + chunk] = src[s0:s0 + chunk].to(self.device, dtype)
         return view
+
+    def _rows4_ok(self, t):
+        """Rows the likelihood kernels can walk in 16-byte chunks over G rounded up to 4: a pitch that covers it and keeps
+        every row on 16 (counts) / 4 (mask) bytes; the pad columns are the producer's to keep zero."""
+        return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= (self.G + 3) // 4 * 4
 
     @classmethod
     def from_tensors(cls, data, size_factors, goodloc, conditions=None, predictors=None, minweight=0.0, repitch=False):
@@ -130,10 +135,11 @@ class DeviceDataset:
         self.minweight = minweight
         self.device = data.device
         self.n, self.G = data.shape
-        if repitch and self.G % 4:
-            if data.stride(0) % 4:
+        if repitch:
+            ld = ops.rows_pitch(self.G)
+            if data.stride(0) != ld:
                 data = self._pitched(data, data.dtype)
-            if goodloc.stride(0) % 4:
+            if goodloc.stride(0) != ld:
                 goodloc = self._pitched(goodloc, goodloc.dtype)
         self.data, self.size_factors, self.goodloc = data, size_factors, goodloc
         self.conditions, self.predictors = conditions, predictors
@@ -181,7 +187,7 @@ class DeviceDataset:
         for what it is: absent.  Only a dataset wrapped around contiguous tensors at a gene count that is not a multiple of
         4 (from_tensors without repitch) makes padded copies here, once, and then holds counts and mask twice."""
         g4 = (self.G + 3) // 4 * 4
-        if self.data.stride(0) == g4 and self.goodloc.stride(0) == g4:  # (a multiple of 4, or rows padded at construction)
+        if self._rows4_ok(self.data) and self._rows4_ok(self.goodloc):  # (a multiple of 4, or rows padded at construction)
             return self.data, self.goodloc
         c = self.__dict__.get("_rows4")
         if c is None:
@@ -255,7 +261,7 @@ class DeviceDataset:
             return t
 
         def rows4(key, dtype):
-            g4 = (self.G + 3) // 4 * 4
+            g4 = ops.rows_pitch(self.G)
             if g4 == self.G:
                 return get(key, (n, self.G), dtype)
             full = bufs.get(key + ".rows4")

@@ -1032,10 +1032,10 @@ class StepEngine:
         x_nb = gl_nb = None
         if G4 != G and cfg["recon_loss"] in ("nb", "zinb") and self.rows4_on:
             if x is None:
-                wide4 = batch["x_full"].stride(0) == G4 and batch["goodloc_full"].stride(0) == G4
+                wide4 = all(t.stride(0) >= G4 and t.stride(0) % 4 == 0 for t in (batch["x_full"], batch["goodloc_full"]))
             else:
                 x_nb, gl_nb = x, batch["goodloc"]
-                if not (x_nb.stride() == (G4, 1) and gl_nb.stride() == (G4, 1)):
+                if not all(t.stride(1) == 1 and t.stride(0) >= G4 and t.stride(0) % 4 == 0 for t in (x_nb, gl_nb)):
                     x_nb = self.buf("x.rows4", (B, G4), F32, zero=True)[:, :G]
                     x_nb.copy_(x)
                     gl_nb = self.buf("goodloc.rows4", (B, G4), batch["goodloc"].dtype, zero=True)[:, :G]

@@ -500,7 +500,8 @@ class Celligner2(nn.Module):
             # 4 elements apart, pad columns zero / masked: the likelihood kernels read them where they are)
             G4 = (x.shape[1] + 3) // 4 * 4
             pitched = (G4 != x.shape[1] and xin is not None and self.recon_loss in ("nb", "zinb") and goodloc is not None
-                       and x.dtype == torch.float32 and x.stride() == (G4, 1) and goodloc.stride() == (G4, 1))
+                       and x.dtype == torch.float32
+                       and all(t.stride(1) == 1 and t.stride(0) >= G4 and t.stride(0) % 4 == 0 for t in (x, goodloc)))
             if not pitched:
                 x = x.float().contiguous()
                 goodloc = goodloc.contiguous() if goodloc is not None else torch.ones_like(x, dtype=torch.bool)

@@ -93,6 +93,7 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     from celligner2_amd.model import Celligner2
     N, B, L, C = 600, 256, 12, 3
     G4 = (G + 3) // 4 * 4
+    LD = (G + 127) // 128 * 128   # ops.rows_pitch: the dataset's rows start on 128-byte lines
     g = torch.Generator(device="cuda")
     g.manual_seed(G)
     X = torch.poisson(torch.exp(torch.randn(1, G, device="cuda", generator=g) + 0.5).expand(N, G).contiguous(), generator=g)
@@ -100,8 +101,8 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     cond = torch.zeros(N, C, dtype=torch.int64, device="cuda")
     cond[torch.arange(N, device="cuda"), torch.randint(0, C, (N,), device="cuda", generator=g)] = 1
     data = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None, repitch=True)
-    assert data.data.stride(0) == G4 and data.goodloc.stride(0) == G4 and torch.equal(data.data, X)
-    assert data.data.untyped_storage().nbytes() == N * G4 * 4  # the padded matrix and nothing else
+    assert data.data.stride(0) == LD and data.goodloc.stride(0) == LD and torch.equal(data.data, X)
+    assert data.data.untyped_storage().nbytes() == N * LD * 4  # the padded matrix and nothing else
     plain = DeviceDataset.from_tensors(X, X.sum(1), good, cond, None)  # contiguous rows: the legacy form
     idx = torch.randperm(N, device="cuda", generator=g)[:B]
     eps = torch.randn(B, L, device="cuda", generator=g)
@@ -132,9 +133,9 @@ def test_nb_on_resident_rows_at_a_gene_count_that_is_not_a_multiple_of_4(precisi
     res = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=True, **spec))
     assert res["x_full"] is data.data and res["goodloc_full"] is data.goodloc and "_rows4" not in data.__dict__
     gat = dict(data.gather(idx, apply_log=True, nb_const=True, resident_rows=False, **spec))
-    assert gat["x"].stride(0) == G4 and gat["goodloc"].stride(0) == G4 and torch.equal(gat["x"], X[idx])
+    assert gat["x"].stride(0) == LD and gat["goodloc"].stride(0) == LD and torch.equal(gat["x"], X[idx])
     assert torch.equal(gat["goodloc"], good[idx])
-    full = gat["x"].as_strided((B, G4), (G4, 1), gat["x"].storage_offset())
+    full = gat["x"].as_strided((B, LD), (LD, 1), gat["x"].storage_offset())
     assert float(full[:, G:].abs().max()) == 0.0  # the pad travelled with the rows
     ten = dict(plain.gather(idx, apply_log=True, nb_const=True, resident_rows=False, **spec))
     ten["x"], ten["goodloc"] = ten["x"].contiguous(), ten["goodloc"].contiguous()
