@@ -39,6 +39,20 @@ __device__ __forceinline__ int64_t shadow_index(const c2_adam_tensor& t, int64_t
 }
 __device__ __forceinline__ void store_shadows(const c2_adam_tensor& t, int64_t i, const f32x4& p) {
     u32x2 pk;
+    if (t.shadow_cols & 3) {  // a width that is not a multiple of 4: a chunk of four may straddle rows -- element by element
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t si = shadow_index(t, i + e);
+            if (t.shadow_f16) {
+                reinterpret_cast<f16_t*>(t.shadow_bf16)[si] = (f16_t)p[e];
+            } else {
+                const bf16_t hb = f2bf(p[e]);
+                reinterpret_cast<bf16_t*>(t.shadow_bf16)[si] = hb;
+                if (t.shadow_lo) reinterpret_cast<bf16_t*>(t.shadow_lo)[si] = f2bf(p[e] - bf2f(hb));
+            }
+        }
+        return;
+    }
     i = shadow_index(t, i);  // (a chunk of four never straddles rows: shadow_cols % 4 == 0)
     if (t.shadow_f16) {  // an IEEE-half copy (the encoder's first layer in bf16 mode): no low plane
         pk[0] = pack2<f16_t>(p[0], p[1]);
@@ -189,9 +203,9 @@ static int adam_launch(const c2_adam_tensor* desc_host, int n_tensors, const Ada
             if (d.n == 0) continue;
             C2_CHECK(d.p && d.g && d.m && d.v && d.n > 0, "bad tensor descriptor");
             C2_CHECK(!d.shadow_lo || d.shadow_bf16, "shadow_lo without the high plane");
-            C2_CHECK(d.shadow_cols == 0 || (d.shadow_cols > 0 && d.shadow_cols % 4 == 0 && d.shadow_ld >= d.shadow_cols &&
-                                            d.shadow_ld % 4 == 0 && d.n % d.shadow_cols == 0),
-                     "pitched shadows need shadow_cols % 4 == 0, shadow_ld % 4 == 0 >= shadow_cols, n a whole number of rows");
+            C2_CHECK(d.shadow_cols == 0 || (d.shadow_cols > 0 && d.shadow_ld >= d.shadow_cols && d.shadow_ld % 4 == 0 &&
+                                            d.n % d.shadow_cols == 0),
+                     "pitched shadows need shadow_ld % 4 == 0 >= shadow_cols and n a whole number of rows");
             C2_CHECK(!(d.shadow_f16 && d.shadow_lo), "an f16 shadow has no low plane");
             tab.t[tab.n] = d;
             tab.first_block[tab.n] = blocks;

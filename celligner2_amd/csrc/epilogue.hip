@@ -1101,7 +1101,18 @@ __global__ __launch_bounds__(256) void gemv_bias_kernel(const float* __restrict_
         const f32x4 acc = (a0 + a1) + (a2 + a3);
         a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     } else {
-        for (int64_t k = threadIdx.x; k < K; k += 256) a += w[k] * c[k];
+        // rows that start on 4 bytes only (a gene count that is not a multiple of 4): eight independent loads in flight
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int64_t k = threadIdx.x;
+        for (; k + 7 * 256 < K; k += 8 * 256) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = __builtin_nontemporal_load(w + k + 256 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += wv[u] * c[k + 256 * u];
+        }
+        for (; k < K; k += 256) s[0] += w[k] * c[k];
+        a = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     a = block_sum<256>(a, red);
     if (threadIdx.x == 0) out[n] = a + (bias ? bias[n] : 0.f);

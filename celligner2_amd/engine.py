@@ -342,7 +342,7 @@ class StepEngine:
         if sh is not None:
             # (a copy in padded storage: the kernel maps its flat index through the row pitch when the width is a multiple
             # of 4; else weight() converts again when the version has moved)
-            if sh.is_contiguous() or (sh.dim() == 2 and sh.shape[1] % 4 == 0 and sh.stride(0) % 4 == 0 and sh.stride(1) == 1):
+            if sh.is_contiguous() or (sh.dim() == 2 and sh.stride(0) % 4 == 0 and sh.stride(1) == 1):
                 return sh
             return None
         # (planes in padded storage -- a width that is not a multiple of 8 -- are not dense: the kernel's flat indexing
@@ -364,7 +364,7 @@ class StepEngine:
         (planes in padded storage); None otherwise -- the engine then splits the weight again when its version has moved."""
         if hi.is_contiguous() and lo.is_contiguous():
             return (hi, lo)
-        if hi.shape[1] % 4 == 0 and hi.stride(0) % 4 == 0 and hi.stride(1) == 1 and lo.stride() == hi.stride():
+        if hi.stride(0) % 4 == 0 and hi.stride(1) == 1 and lo.stride() == hi.stride():
             return (hi, lo)
         return None
 
@@ -574,6 +574,8 @@ class StepEngine:
         w = self.weight(wname)
         M, K, R = dy.shape[0], w.shape[1], w.shape[0]
         pl = dy.dtype == F32 and w.dtype == F32 and bool(self._planes_fit("dgrad", M, K, R))
+        if not pl and self._padded_width(dy):
+            R = self._padded_width(dy)  # (_dgrad reduces a 2-byte pair over the padded length)
         return ops.pick_nslab(M, K, R, dy.dtype, self.x3, planes=pl)
 
     def _linear_slabs(self, key, a, wname, B):
@@ -964,8 +966,9 @@ class StepEngine:
                 if xb is None or xb.dtype != xt or xb.shape != xf.shape:
                     raise ValueError("an f16 xin_full needs its bf16 twin xinb_full (the weight gradient's operand)")
                 wg_in = (xb, r32)
+            Gr = self._padded_width(xf) or G  # (the forward reduces over the rows' zero-padded length)
             if not (xt == torch.bfloat16 and xf.dtype == ft and B % 8 == 0
-                    and ops.gemm_tile(xt, B, H0, G) == 256 and ops.gemm_tile(xt, H0, G, B) == 256):
+                    and ops.gemm_tile(xt, B, H0, Gr) == 256 and ops.gemm_tile(xt, H0, G, B) == 256):
                 raise ValueError("xin_full / row_index32 need bf16 mode and a first layer the 256x256 GEMM takes; "
                                  "gather the encoder input instead (DeviceDataset.gather(resident_xin=False))")
             rows = (xf, r32)
@@ -1048,8 +1051,10 @@ class StepEngine:
         half_logits = (self.half_logits_on and self.head_t == torch.bfloat16 and cfg["recon_loss"] == "nb" and not wide4 and want_db
                        and d.dtype == torch.bfloat16 and ops.nb_logits_f16_ok(B, G))
         if wide4:
+            fresh = ("logits4" not in self._pool) or ((B, G4), F32) not in self._pool["logits4"]
             logits4 = self.buf("logits4", (B, G4))
-            logits4[:, G:].fill_(-float("inf"))
+            if fresh:  # (the GEMM writes G columns: the pad keeps what it is given once)
+                logits4[:, G:].fill_(-float("inf"))
             logits = self._ws["logits"] = logits4[:, :G]
         elif half_logits:
             logits = self.abuf("logits16", (B, G), torch.float16)  # (rows a padded pitch apart: aligned stores and loads)

@@ -731,7 +731,7 @@ def _adam_table(entries):
                     sh, lo = sh[0], sh[1]
             assert sh.numel() == p.numel()
             if not sh.is_contiguous():  # rows a pitch apart (zero-padded storage): the kernel maps its flat index
-                assert sh.dim() == 2 and sh.stride(1) == 1 and sh.shape[1] % 4 == 0 and sh.stride(0) % 4 == 0
+                assert sh.dim() == 2 and sh.stride(1) == 1 and sh.stride(0) % 4 == 0
                 assert lo is None or (lo.shape == sh.shape and lo.stride() == sh.stride())
                 cols, ld = sh.shape[1], sh.stride(0)
             else:

@@ -400,7 +400,8 @@ class Trainer:
         def in_place(n):  # both first-layer GEMMs (forward [n,H0] over G, weight gradient [H0,G] over n) on the 256x256 kernel
             from . import ops
             return (nb and xin_dtype in (torch.bfloat16, torch.float16) and n % 8 == 0
-                    and ops.gemm_tile(torch.bfloat16, n, H0, G) == 256 and ops.gemm_tile(torch.bfloat16, H0, G, n) == 256)
+                    and ops.gemm_tile(torch.bfloat16, n, H0, ops.pitch2(G)) == 256  # (reduced over the rows' padded length)
+                    and ops.gemm_tile(torch.bfloat16, H0, G, n) == 256)
 
         return _Loader(data, batch_size, weights, n_samples, self.rng, xin_dtype, log_in, self.world, nb, in_place,
                        centered=eng.center_input, xin2=eng.fwd16 is not None)

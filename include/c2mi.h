@@ -357,8 +357,8 @@ typedef struct {
     void* shadow_lo;   /* NULL, or [n] bf16: the low plane lo = bf16(p - hi) next to shadow_bf16 = hi = bf16(p), the
                           C2_BF16X3P operand form of the fp32 weights of the narrow layers */
     int32_t shadow_f16; /* non-zero: shadow_bf16 addresses [n] IEEE halves (C2_F16) instead of bf16; no shadow_lo */
-    int32_t shadow_cols; /* 0: the shadows are dense [n]; else the parameter is a matrix with this many columns (% 4 == 0) */
-    int64_t shadow_ld;   /* and its shadows have rows shadow_ld elements apart (planes in zero-padded storage) */
+    int32_t shadow_cols; /* 0: the shadows are dense [n]; else the parameter is a matrix with this many columns */
+    int64_t shadow_ld;   /* and its shadows have rows shadow_ld (% 4 == 0) elements apart (copies in zero-padded storage) */
 } c2_adam_tensor;
 int c2_adam_step(const c2_adam_tensor* desc_host, int n_tensors, double lr, double beta1, double beta2, double eps,
                  double weight_decay, double clip_value, int64_t step_t, void* stream);

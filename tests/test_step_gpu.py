@@ -103,13 +103,7 @@ def _run_case(z, meta, precision, tol):
                 assert gu.relerr(p.detach().cpu().numpy(), pref) < 1e-4, (k, s)
         else:  # bf16 shadows follow the fp32 master weights bit for bit
             for n, sh in eng._shadow.items():
-                if not sh.is_contiguous() and sh.shape[1] % 4:
-                    # rows padded to 8 elements at a width that is not a multiple of 4: converted by the engine at the next
-                    # use, not by Adam (whose four-element chunks would straddle rows)
-                    stale = sh.clone()
-                    sh = eng.weight(n)
-                    assert not torch.equal(stale, sh), n
-                # (dense copies, and padded ones at widths that are multiples of 4, were refreshed by the Adam kernel itself)
+                # (dense copies and copies in padded storage alike were refreshed by the Adam kernel itself)
                 assert torch.equal(sh, dict(model.named_parameters())[n].detach().to(sh.dtype)), n
 
 
