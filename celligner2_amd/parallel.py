@@ -87,29 +87,18 @@ class DataParallelStep:
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
-    def _stage(self, n, dtype, device):
-        """A persistent staging chunk (1/world of the largest bucket: 20 MB at 19k genes x 1024 on 8 ranks).  The
-        collectives below are given separate input and output buffers: RCCL also defines in-place forms, but no
-        multi-GPU node was available to run them on, and the copy of one chunk is ~5 us."""
-        buf = self.__dict__.get("_stage_buf")
-        if buf is None or buf.numel() < n or buf.dtype != dtype or buf.device != device:
-            buf = self.__dict__["_stage_buf"] = torch.empty(n, dtype=dtype, device=device)
-        return buf[:n]
-
     def _reduce_scatter_(self, flat):
         """Chunk `rank` of `flat` (world_size equal chunks) becomes the SUM over ranks of that chunk; the other chunks
-        are left as they were (un-reduced)."""
+        are left as they were (un-reduced).  The collective's in-place form: the output IS chunk `rank` of the input
+        (receive address = send address + rank * count, which RCCL defines as in place), so there is no staging chunk
+        and nothing to copy back."""
         n = flat.numel() // self.world_size
-        out = self._stage(n, flat.dtype, flat.device)
-        dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat[self.rank * n:(self.rank + 1) * n].copy_(out)
+        dist.reduce_scatter_tensor(flat[self.rank * n:(self.rank + 1) * n], flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def _all_gather_(self, flat):
-        """Every rank's chunk `rank` of `flat` is distributed to all."""
+        """Every rank's chunk `rank` of `flat` is distributed to all (in place: the input is that chunk of the output)."""
         n = flat.numel() // self.world_size
-        mine = self._stage(n, flat.dtype, flat.device)
-        mine.copy_(flat[self.rank * n:(self.rank + 1) * n])
-        dist.all_gather_into_tensor(flat, mine, group=self.group)
+        dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
 
     # -- the sharded form: arena bookkeeping
     def set_arena(self, grad_flat, param_flat, buckets):
