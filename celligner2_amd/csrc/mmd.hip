@@ -500,6 +500,9 @@ __global__ __launch_bounds__(64, FAST ? 3 : 1) void mmd_tile_kernel(const TF* __
 #ifndef C2_MMD_SPLIT_GRAM
 #define C2_MMD_SPLIT_GRAM 1
 #endif
+#ifndef C2_MMD_POW
+#define C2_MMD_POW 1
+#endif
 __device__ __forceinline__ void split3(float x, bf16_t& h, bf16_t& m, bf16_t& l) {
     h = f2bf(x);
     const float r1 = x - bf2f(h);
@@ -733,27 +736,84 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
         const float dmin_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmin), 63));
         MMD_T(2)
         // beta_k = 1/(2 alpha_k) folded at compile time in fp32, as the reference forms it (losses.py:156);
-        // exp(-beta d) = exp2(-beta log2(e) d) on v_exp_f32; terms in the reference's order
-#define C2_MMD_TERM(ALPHA)                                                  \
-    {                                                                       \
-        constexpr float bk = 1.0f / (2.0f * (ALPHA));                       \
-        constexpr float ck = -bk * 1.4426950408889634f;                     \
-        if (-ck * dmin_u < C2_MMD_SKIP_T) {                                 \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                 \
-                const f32x2 arg = ck * dd[e];                               \
-                f32x2 ex;                                                   \
-                ex[0] = __builtin_amdgcn_exp2f(arg[0]);                     \
-                ex[1] = __builtin_amdgcn_exp2f(arg[1]);                     \
-                S[e] += ex;                                                 \
-                Wp[e] = (2.f * bk) * ex + Wp[e];                            \
-            }                                                               \
-        }                                                                   \
+        // exp(-beta d) = exp2(-beta log2(e) d) on v_exp_f32.  The exponential is the quarter-rate instruction this
+        // kernel sits on, and the reference's bandwidths are multiples of each other: with C2_MMD_POW (default 1) only
+        // alpha = 1e6, 1e4, 100, 35, 30, 20 (and the rarely live alpha <= 0.1) are exponentials, the others are small
+        // integer powers of those on packed multiplies -- 1e5 = (1e6)^10, 1e3 = (1e4)^10, 25 = (100)^4, 15 = (30)^2,
+        // 10 = (20)^2, 5 = (20)^4, 1 = (20)^20: six exponentials per pair instead of thirteen.  A power n carries n
+        // roundings of 2^-24 (n <= 20 from an exponential: 1.2e-6 relative on one of the 19 terms).
+#define C2_MMD_ACTIVE(ALPHA) ((1.0f / (2.0f * (ALPHA))) * 1.4426950408889634f * dmin_u < C2_MMD_SKIP_T)
+#define C2_MMD_EXP(ALPHA, X)                                                                 \
+    {                                                                                        \
+        constexpr float ck = -(1.0f / (2.0f * (ALPHA))) * 1.4426950408889634f;               \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                      \
+            const f32x2 arg = ck * dd[e];                                                    \
+            X[e][0] = __builtin_amdgcn_exp2f(arg[0]);                                        \
+            X[e][1] = __builtin_amdgcn_exp2f(arg[1]);                                        \
+        }                                                                                    \
     }
+#define C2_MMD_ADD(ALPHA, X)                                                                 \
+    {                                                                                        \
+        constexpr float bk = 1.0f / (2.0f * (ALPHA));                                        \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                      \
+            S[e] += X[e];                                                                    \
+            Wp[e] = (2.f * bk) * X[e] + Wp[e];                                               \
+        }                                                                                    \
+    }
+#define C2_MMD_TERM(ALPHA)                  \
+    if (C2_MMD_ACTIVE(ALPHA)) {             \
+        f32x2 x_[8];                        \
+        C2_MMD_EXP(ALPHA, x_)               \
+        C2_MMD_ADD(ALPHA, x_)               \
+    }
+#define C2_MMD_SQ(X) _Pragma("unroll") for (int e = 0; e < 8; ++e) X[e] = X[e] * X[e];
+#define C2_MMD_P5(X) _Pragma("unroll") for (int e = 0; e < 8; ++e) { const f32x2 q_ = X[e] * X[e]; X[e] = (q_ * q_) * X[e]; }
         C2_MMD_TERM(1e-6f) C2_MMD_TERM(1e-5f) C2_MMD_TERM(1e-4f) C2_MMD_TERM(1e-3f) C2_MMD_TERM(1e-2f)
-        C2_MMD_TERM(1e-1f) C2_MMD_TERM(1.f) C2_MMD_TERM(5.f) C2_MMD_TERM(10.f) C2_MMD_TERM(15.f)
+        C2_MMD_TERM(1e-1f)
+#if C2_MMD_POW
+        if (C2_MMD_ACTIVE(20.f)) {
+            f32x2 x[8];
+            C2_MMD_EXP(20.f, x) C2_MMD_ADD(20.f, x)
+            if (C2_MMD_ACTIVE(10.f)) {
+                C2_MMD_SQ(x) C2_MMD_ADD(10.f, x)
+                if (C2_MMD_ACTIVE(5.f)) {
+                    C2_MMD_SQ(x) C2_MMD_ADD(5.f, x)
+                    if (C2_MMD_ACTIVE(1.f)) { C2_MMD_P5(x) C2_MMD_ADD(1.f, x) }
+                }
+            }
+        }
+        if (C2_MMD_ACTIVE(30.f)) {
+            f32x2 x[8];
+            C2_MMD_EXP(30.f, x) C2_MMD_ADD(30.f, x)
+            if (C2_MMD_ACTIVE(15.f)) { C2_MMD_SQ(x) C2_MMD_ADD(15.f, x) }
+        }
+        C2_MMD_TERM(35.f)
+        if (C2_MMD_ACTIVE(100.f)) {
+            f32x2 x[8];
+            C2_MMD_EXP(100.f, x) C2_MMD_ADD(100.f, x)
+            if (C2_MMD_ACTIVE(25.f)) { C2_MMD_SQ(x) C2_MMD_SQ(x) C2_MMD_ADD(25.f, x) }
+        }
+        if (C2_MMD_ACTIVE(1e4f)) {
+            f32x2 x[8];
+            C2_MMD_EXP(1e4f, x) C2_MMD_ADD(1e4f, x)
+            if (C2_MMD_ACTIVE(1e3f)) { C2_MMD_P5(x) C2_MMD_SQ(x) C2_MMD_ADD(1e3f, x) }
+        }
+        if (C2_MMD_ACTIVE(1e6f)) {
+            f32x2 x[8];
+            C2_MMD_EXP(1e6f, x) C2_MMD_ADD(1e6f, x)
+            if (C2_MMD_ACTIVE(1e5f)) { C2_MMD_P5(x) C2_MMD_SQ(x) C2_MMD_ADD(1e5f, x) }
+        }
+#else
+        C2_MMD_TERM(1.f) C2_MMD_TERM(5.f) C2_MMD_TERM(10.f) C2_MMD_TERM(15.f)
         C2_MMD_TERM(20.f) C2_MMD_TERM(25.f) C2_MMD_TERM(30.f) C2_MMD_TERM(35.f) C2_MMD_TERM(100.f)
         C2_MMD_TERM(1e3f) C2_MMD_TERM(1e4f) C2_MMD_TERM(1e5f) C2_MMD_TERM(1e6f)
+#endif
 #undef C2_MMD_TERM
+#undef C2_MMD_ACTIVE
+#undef C2_MMD_EXP
+#undef C2_MMD_ADD
+#undef C2_MMD_SQ
+#undef C2_MMD_P5
 #ifdef C2_MMD_DBG
         asm volatile("s_nop 0" :: "v"(S[0][0]), "v"(Wp[7][1]));
         MMD_T(3)
