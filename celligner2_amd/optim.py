@@ -39,16 +39,35 @@ class FusedAdam(torch.optim.Optimizer):
         return self._grad_sync is not None and getattr(self._grad_sync, "sharded", False)
 
     def state_dict(self):
-        """Refused in the sharded form: every rank holds full-shape moment tensors but maintains only the elements of its
-        own chunks (parallel.DataParallelStep(shard_optimizer=True)), so what any single rank would save is mostly stale
-        -- resuming from it, or changing the world size, would silently diverge.  Checkpoint the MODEL (its state_dict is
-        complete on every rank after each step), or run the all-reduce form (shard_optimizer=False), whose optimizer
-        state is whole on every rank."""
-        if self._sharded():
-            raise RuntimeError("FusedAdam.state_dict(): the optimizer state is sharded over the ranks (shard_optimizer=True): "
-                               "each rank maintains the moments of its own chunks only; save the model's state_dict, or "
-                               "use shard_optimizer=False for a checkpointable optimizer")
-        return super().state_dict()
+        """The usual dictionary.  In the sharded form (parallel.DataParallelStep(shard_optimizer=True)) every rank holds
+        full-shape moment tensors but maintains only the elements of its own chunks, so the call is a COLLECTIVE there:
+        every rank must make it; each contributes the elements it maintains (zeros elsewhere) to a SUM over the ranks, and
+        every rank gets the complete moments back -- what the all-reduce form, or a single process, would have saved.
+        `load_state_dict` needs nothing special: it puts whole moments on every rank, of which each goes on maintaining
+        its own elements.  Before the first backward pass (no arena yet) the state is whatever was loaded, whole."""
+        sd = super().state_dict()
+        if not self._sharded():
+            return sd
+        params = [p for g in self.param_groups for p in g["params"]]
+        state = {}
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            own = self._grad_sync.owned_slices(p)
+            if own is None:  # no step yet: nothing is partial
+                state[i] = st
+                continue
+            whole = dict(st)
+            for key in ("exp_avg", "exp_avg_sq"):
+                full = torch.zeros_like(st[key], memory_format=torch.contiguous_format)
+                src = st[key].reshape(-1)
+                for i0, i1 in own:
+                    full.view(-1)[i0:i1].copy_(src[i0:i1])
+                whole[key] = self._grad_sync.allreduce_scalars(full)
+            state[i] = whole
+        sd["state"] = state
+        return sd
 
     @staticmethod
     def _hyper_of(group):

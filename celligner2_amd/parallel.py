@@ -138,6 +138,23 @@ class DataParallelStep:
                     out.append((p.view(-1)[i0:i1], g.view(-1)[i0:i1], m.view(-1)[i0:i1], v.view(-1)[i0:i1], None))
         return out
 
+    def owned_slices(self, p):
+        """Element ranges [(i0, i1), ...] of the flattened parameter `p` (a view of the flat parameter buffer, which is
+        laid out like the gradient arena) whose optimizer state this rank maintains; None before the arena exists."""
+        if self._arena is None:
+            return None
+        _, param_flat, buckets = self._arena
+        off = (p.data_ptr() - param_flat.data_ptr()) // 4
+        if not (0 <= off and off + p.numel() <= param_flat.numel()):
+            raise RuntimeError("parameter is not a view of the engine's flat parameter buffer")
+        out = []
+        for lo, hi in buckets:
+            n = (hi - lo) // self.world_size
+            s, e = max(off, lo + self.rank * n), min(off + p.numel(), lo + (self.rank + 1) * n)
+            if s < e:
+                out.append((s - off, e - off))
+        return out
+
     def allgather_params(self):
         """After the sharded Adam: every bucket of the flat parameter buffer is completed from the ranks' chunks
         (stream-ordered on the compute stream: the next forward reads the parameters)."""

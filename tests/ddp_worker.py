@@ -117,17 +117,17 @@ def main():
                          {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
             opt.step()
         torch.cuda.synchronize()
-        return first[0].cpu().numpy().astype(np.float64), first[1]
+        return first[0].cpu().numpy().astype(np.float64), first[1], opt
 
     ref_l = ref_g = ref_m = None
     if rank == 0:
         ref_m = build()
-        ref_l, ref_g = run(ref_m, slice(0, B))
+        ref_l, ref_g, ref_opt = run(ref_m, slice(0, B))
     m = build()
     comm = DataParallelStep(shard_optimizer=shard)
     comm.attach_model(m)
     per = B // world
-    losses, grads = run(m, slice(rank * per, (rank + 1) * per), sync=comm)
+    losses, grads, opt = run(m, slice(rank * per, (rank + 1) * per), sync=comm)
     assert comm.defer_last and comm.deferred_range() is None
     assert comm._host_backend == (backend != "nccl") and m._engine().exchange
     if shard:
@@ -137,6 +137,7 @@ def main():
         assert all(lo_ <= p.data_ptr() < hi_ for p in m.parameters()), "parameters are views of the flat buffer"
         assert all((hi - lo) % (64 * world) == 0 for lo, hi in eng.buckets)
     m._engine().check_status()
+    sd = opt.state_dict()  # (sharded form: a collective -- every rank gets the complete moments)
     if os.environ.get("C2_DDP_DUMP") and rank == 0:  # (debugging: the workspaces of the last backward, rank 0's rows)
         we, wr = m._engine()._ws, ref_m._engine()._ws
         for key in sorted(we, key=str):
@@ -185,6 +186,16 @@ def main():
             if err > tol_p and dabs > float(os.environ.get("C2_DDP_PARAM_TOL_LR", "2e-2")) * 1e-3 * NSTEPS:
                 ok = False
                 print("MISMATCH param after Adam", n, err)
+        # Adam's moments after the last step: whole on this rank (in the sharded form through state_dict()'s SUM over ranks)
+        ref_sd = ref_opt.state_dict()
+        assert sorted(sd["state"]) == sorted(ref_sd["state"])
+        for i, st in ref_sd["state"].items():
+            for key in ("exp_avg", "exp_avg_sq"):
+                den = st[key].abs().max().item()
+                err = (sd["state"][i][key] - st[key]).abs().max().item() / max(den, 1e-30)
+                if sd["state"][i]["step"] != st["step"] or err > (5e-2 if precision == "bf16" else 1e-3):
+                    ok = False
+                    print("MISMATCH optimizer state", i, key, err, sd["state"][i]["step"], st["step"])
         print("losses ddp", losses, "single", ref_l, "worst first-step gradient error", locals().get("worst_g"))
     _finish(ok, backend == "nccl")
 

@@ -71,6 +71,24 @@ def _worker(rank, world, port, out):
         for r in range(world):
             seg = pflat[lo + r * n:lo + (r + 1) * n]
             assert torch.equal(seg, torch.arange(lo + r * n, lo + (r + 1) * n, dtype=torch.float32) + 1000 * r)
+    # the sharded optimizer's state_dict(): a collective that returns the complete moments on every rank -- each rank's
+    # own elements from that rank, whatever stale values the others hold there
+    from celligner2_amd.optim import FusedAdam
+    pa, pb = pflat[40:64 * world + 30], pflat[64 * world + 30:64 * world * 3]  # two "parameters", views of the flat buffer
+    opt = FusedAdam([torch.nn.Parameter(pa), torch.nn.Parameter(pb)], grad_sync=sh)
+    plist = [q for g_ in opt.param_groups for q in g_["params"]]
+    assert [sh.owned_slices(q) for q in plist] == {0: [[(0, 24), (88, 118)], [(0, 98)]], 1: [[(24, 88)], [(98, 226)]]}[rank]
+    for q in plist:  # every rank's moments: 100 * (rank + 1) + element index inside its own elements, junk elsewhere
+        mine_m = torch.full((q.numel(),), -7.0)
+        for i0, i1 in sh.owned_slices(q):
+            mine_m[i0:i1] = 100.0 * (rank + 1) + torch.arange(i0, i1, dtype=torch.float32)
+        opt.state[q] = dict(step=5, exp_avg=mine_m, exp_avg_sq=2 * mine_m)
+    sd = opt.state_dict()
+    for i, want_owner in enumerate(([0] * 24 + [1] * 64 + [0] * 30, [0] * 98 + [1] * 128)):
+        want = torch.tensor([100.0 * (o + 1) + k for k, o in enumerate(want_owner)])
+        assert sd["state"][i]["step"] == 5
+        assert torch.equal(sd["state"][i]["exp_avg"], want) and torch.equal(sd["state"][i]["exp_avg_sq"], 2 * want), (rank, i)
+        assert torch.equal(opt.state[plist[i]]["exp_avg"][:1], torch.tensor([-7.0 if rank == 1 else 100.0])), "state untouched"
     # the decomposition identity, with the oracle as the per-rank compute
     rng = np.random.default_rng(0)
     B, G, C, P, L = 16, 40, 2, 3, 4
@@ -141,10 +159,9 @@ def test_loader_shards_global_batches():
         assert fa == ff[:per] and fb == ff[per:2 * per]
 
 
-def test_sharded_optimizer_refuses_to_serialise_its_partial_state():
-    """shard_optimizer=True: a rank maintains Adam's moments only inside its own chunks, so FusedAdam.state_dict() on any
-    rank would save mostly stale values without an error -- it raises instead; the all-reduce form serialises as usual."""
-    import pytest
+def test_sharded_optimizer_state_before_the_first_step_is_whole():
+    """shard_optimizer=True before any backward pass built the arena: nothing is partial yet, state_dict() is the plain one
+    (the consolidation over ranks is covered by the two-rank worker above and by tests/ddp_worker.py on the GPU)."""
     import torch
     from celligner2_amd.optim import FusedAdam
 
@@ -154,8 +171,13 @@ def test_sharded_optimizer_refuses_to_serialise_its_partial_state():
         def __init__(self, sharded):
             self.sharded = sharded
 
+        def owned_slices(self, p):
+            return None
+
     p = torch.nn.Parameter(torch.zeros(4))
-    with pytest.raises(RuntimeError, match="sharded over the ranks"):
-        FusedAdam([p], grad_sync=Comm(True)).state_dict()
+    opt = FusedAdam([p], grad_sync=Comm(True))
+    opt.state[p] = dict(step=3, exp_avg=torch.ones(4), exp_avg_sq=torch.full((4,), 2.0))
+    sd = opt.state_dict()
+    assert sd["state"][0]["step"] == 3 and torch.equal(sd["state"][0]["exp_avg"], torch.ones(4))
     sd = FusedAdam([p], grad_sync=Comm(False)).state_dict()
     assert sd["param_groups"][0]["lr"] == 1e-3 and FusedAdam([p]).state_dict()["state"] == {}
