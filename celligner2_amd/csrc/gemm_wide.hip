@@ -292,11 +292,15 @@ __device__ __forceinline__ void wait_loads(int c) {
 // IDX: 0 plain operands; 1 the rows of the (RC) A operand are read through a.rows (forward of a batch that lives in a
 // resident matrix); 2 the k-rows of the (XC) B operand are (its weight gradient).  The per-lane DMA source address
 // carries the row: for IDX 1 once per block, for IDX 2 per K-tile from eight wave-uniform (scalar) index loads.
-template <bool A_RC, bool B_RC, int NW, int IDX = 0>
+// DD (NW = 4 only): ring depth 2 instead of 4 -- 5 x 16 KB = 80 KB, TWO blocks per CU -- for launches whose blocks reduce
+// over a few K-tiles only (the gene-width layers at the reference's batch of 128: a weight gradient is 298 tiles of two
+// K-tiles each, which at one block per CU ran as a full round and a sixth of a second one; a deep ring has nothing to
+// prefetch there).
+template <bool A_RC, bool B_RC, int NW, int IDX = 0, int DD = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     static_assert(IDX == 0 || (IDX == 1 && A_RC) || (IDX == 2 && !B_RC), "row index on an RC A or an XC B operand");
     constexpr int BX = 32 * NW;             // block tile edge: 256 or 128
-    constexpr int D = NW == 8 ? 2 : 4;
+    constexpr int D = DD ? DD : (NW == 8 ? 2 : 4);
     constexpr int NSLOT = 2 * D + 1;
     constexpr int MI = NW / 2;              // MFMA tiles per wave along M
     constexpr int WN = NW / 2;              // waves along N
@@ -1168,6 +1172,29 @@ static void launch_nw(int layout, const GemmArgs& a, int nslab, hipStream_t stre
         (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
+    }
+    if constexpr (NW == 4) {
+        // short reductions on more blocks than CUs: the shallow ring, two blocks per CU (C2_WIDE_SHALLOW=0: A/B)
+        static const bool shallow_on = []() { const char* e = getenv("C2_WIDE_SHALLOW"); return !(e && e[0] == '0'); }();
+        static const int shallow_kt = []() { const char* e = getenv("C2_WIDE_SHALLOW_KT"); return e ? atoi(e) : 8; }();
+        const int kt = ((a.R < a.r_per_split ? a.R : a.r_per_split) + BK - 1) / BK * (a.A_lo ? 3 : 1);
+        if (shallow_on && layout != 3 && grid.x > 256 && kt <= shallow_kt) {
+            constexpr int LDS2 = 5 * BX * BK * 2;
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, true, 4, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<true, false, 4, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<false, false, 4, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                attr2 = true;
+            }
+            if (layout == 0)
+                hipLaunchKernelGGL((gemm_wide_kernel<true, true, 4, 0, 2>), grid, dim3(256), LDS2, stream, a, tiles_m, tiles_n);
+            else if (layout == 1)
+                hipLaunchKernelGGL((gemm_wide_kernel<true, false, 4, 0, 2>), grid, dim3(256), LDS2, stream, a, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL((gemm_wide_kernel<false, false, 4, 0, 2>), grid, dim3(256), LDS2, stream, a, tiles_m, tiles_n);
+            return;
+        }
     }
     if (layout == 0)
         hipLaunchKernelGGL((gemm_wide_kernel<true, true, NW>), grid, dim3(64 * NW), LDS, stream, a, tiles_m, tiles_n);

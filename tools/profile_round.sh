@@ -23,9 +23,9 @@ bash tools/pmc_step.sh $tag || exit 5
 cp gpurun_out/pmc_step_$tag/r03_gemm_pmc.json $out/ || exit 6
 timeout -k 10 300 python3 bench.py > $out/bench_c4.json 2> $out/bench_c4.err || exit 7
 timeout -k 10 300 python3 bench.py --config c2 --steps 200 --warmup 20 > $out/bench_c2.json 2> $out/bench_c2.err || exit 8
-for cfg in c1 c3 c5; do  # the other configurations of SURVEY.md 8(d): bench lines only
-  steps=200; [ $cfg = c3 ] && steps=20
-  extra=""; [ $cfg = c5 ] && extra="--no-cpu-baseline"  # (the numpy port has no frozen-parameter step)
+for cfg in c1 c3 c5 c4g1 c4z; do  # the other configurations of SURVEY.md 8(d) (+ 19 001 genes, + ZINB): bench lines only
+  steps=200; [ $cfg = c3 -o $cfg = c4g1 -o $cfg = c4z ] && steps=20
+  extra=""; [ $cfg = c5 -o $cfg = c4g1 -o $cfg = c4z ] && extra="--no-cpu-baseline"  # (the numpy port has no frozen-parameter step)
   timeout -k 10 300 python3 bench.py --config $cfg --steps $steps --warmup 10 $extra > $out/bench_$cfg.json 2> $out/bench_$cfg.err || exit 9
 done
 C2_DP_SINGLE_RANK=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $out/bench_c4_dp1_rehearsal.json 2> $out/bench_c4_dp1_rehearsal.err || exit 10
