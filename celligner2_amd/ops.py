@@ -3,6 +3,8 @@
 All tensors live on the GPU; shapes/strides are checked here on the host before any
 kernel is enqueued.  Nothing in this module computes on the CPU.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -112,6 +114,9 @@ def planes_ok(M, N, R, lds=()):
     return gemm_tile(None, M, N, R, planes=True) > 0 and all(int(x) % 8 == 0 for x in lds)
 
 
+_SKINNY_SLABS = int(os.environ.get("C2_SKINNY_SLABS", "64"))
+
+
 def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False):
     """Number of slabs a reduction of length R is split into for an [M,N] output, so that the launch fills the
     256 CUs: >= ~2 blocks per CU of the register-staged 128x128 kernel, one block per CU of the LDS-DMA kernels."""
@@ -124,7 +129,7 @@ def pick_nslab(M, N, R, dtype=torch.float32, x3=False, max_slab=16, planes=False
     if tiles >= target or R <= 4 * bk:
         return 1
     if tiles <= 4 and dtype == torch.bfloat16:
-        max_slab = max(max_slab, 64)  # a gene-width reduction into a one-batch-of-128 output: 4 tiles x 64 slabs fill the chip
+        max_slab = max(max_slab, _SKINNY_SLABS)  # a gene-width reduction into a one-batch-of-128 output: 4 tiles x 64 slabs fill the chip
     n = min(max_slab, (target + tiles - 1) // tiles, max(1, R // (4 * bk)))
     return max(1, n)
 
