@@ -14,7 +14,7 @@ def step_cases():
     out = []
     for f in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(f)[:-4]
-        if name.startswith(("nb_wide_row", "trainer_", "surgery_", "checkpoint_")):
+        if name.startswith(("nb_wide_row", "trainer_", "surgery_", "checkpoint_", "wrapper_")):
             continue
         out.append(name)
     return out
