@@ -276,6 +276,42 @@ __device__ __forceinline__ void store_planes4(bf16_t* hi_p, int64_t plane, const
     *reinterpret_cast<u32x2*>(hi_p + plane) = pl;
 }
 
+// Both kernels are written in PHASES -- every load of the row, the arithmetic, every store -- with no branch between
+// the loads of a phase and none between the stores: columns past the row's end read column 0 and are zeroed by a select,
+// slabs past the last one re-read slab 0 likewise.  Written per 16-byte chunk (load, use, store, next chunk) the
+// compiler keeps each chunk's loads behind the branches of the one before it and opens every chunk with s_waitcnt
+// vmcnt(0) -- which on this architecture also waits for the previous chunk's STORES to come back from memory: a row of
+// 1024 columns cost its wave some sixteen serial round trips to memory (ISA of the round-2 form).
+__device__ __forceinline__ f32x4 sel4(bool keep, const f32x4& v) {
+    return f32x4{keep ? v[0] : 0.f, keep ? v[1] : 0.f, keep ? v[2] : 0.f, keep ? v[3] : 0.f};
+}
+// the row's sums over the slabs at the EPL chunks (valid columns cc[]): the branch on the slab count OUTSIDE the walk over
+// the chunks, groups of four independent loads per chunk, slabs past the end re-read slab 0 and are zeroed
+template <int EPL>
+__device__ __forceinline__ void slab_sums(f32x4 (&h)[EPL], const float* __restrict__ rowp, const int (&cc)[EPL], int nslab,
+                                          int64_t slab_stride) {
+    if (nslab == 1) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f} + *reinterpret_cast<const f32x4*>(rowp + cc[i]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nslab; s0 += 4) {
+        f32x4 t[EPL][4];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                t[i][u] = *reinterpret_cast<const f32x4*>(rowp + cc[i] + (s0 + u < nslab ? s0 + u : 0) * slab_stride);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            h[i] += (sel4(s0 < nslab, t[i][0]) + sel4(s0 + 1 < nslab, t[i][1])) +
+                    (sel4(s0 + 2 < nslab, t[i][2]) + sel4(s0 + 3 < nslab, t[i][3]));
+    }
+}
+#define C2_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70) /* s_waitcnt vmcnt(0): as an instruction the compiler's own counter sees */
+
 template <typename TO, int EPL>
 __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
     const float* __restrict__ Y, int64_t ldy, int nslab, int64_t slab_stride, const float* __restrict__ bias,
@@ -286,35 +322,43 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const int64_t* crow = cond ? cond + row * C : nullptr;
-    f32x4 cache[EPL];
-    float sum = 0.f;
+    bool ok[EPL];
+    int cc[EPL];  // the chunk's first column, or 0 where the chunk lies past the row's end (a valid address: H >= 4)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const int c = (lane + 64 * i) * 4;
-        f32x4 h = {0.f, 0.f, 0.f, 0.f};
-        if (c < H) {
-            // the slabs in groups of four independent loads (a run-time trip count would serialise load and add)
-            for (int s0 = 0; s0 < nslab; s0 += 4) {
-                f32x4 t[4];
+        ok[i] = c < H;
+        cc[i] = ok[i] ? c : 0;
+    }
+    // ---- loads
+    f32x4 cache[EPL];
+    unsigned mb[EPL];
+    slab_sums<EPL>(cache, Y + row * ldy, cc, nslab, slab_stride);
+    if (mask) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    t[u] = (s0 + u < nslab) ? *reinterpret_cast<const f32x4*>(Y + (s0 + u) * slab_stride + row * ldy + c)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-                h += (t[0] + t[1]) + (t[2] + t[3]);
-            }
-            if (bias) h += *reinterpret_cast<const f32x4*>(bias + c);
-            if (crow) {
-                for (int j = 0; j < C; ++j) {
-                    const float cj = (float)crow[j];
-                    if (cj != 0.f) {
+        for (int i = 0; i < EPL; ++i) mb[i] = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + cc[i]);
+    }
+    if (bias) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] += cj * Wc[(int64_t)(c + e) * ldwc + j];
-                    }
-                }
+        for (int i = 0; i < EPL; ++i) cache[i] += *reinterpret_cast<const f32x4*>(bias + cc[i]);
+    }
+    if (crow) {
+        for (int j = 0; j < C; ++j) {
+            const float cj = (float)crow[j];
+            if (cj != 0.f) {
+#pragma unroll
+                for (int i = 0; i < EPL; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cache[i][e] += cj * Wc[(int64_t)(cc[i] + e) * ldwc + j];
             }
         }
-        cache[i] = h;
-        sum += (h[0] + h[1]) + (h[2] + h[3]);
+    }
+    // ---- statistics
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        cache[i] = sel4(ok[i], cache[i]);
+        sum += (cache[i][0] + cache[i][1]) + (cache[i][2] + cache[i][3]);
     }
     float mean = 0.f, rstd = 1.f;
     if (use_ln) {
@@ -322,38 +366,39 @@ __global__ __launch_bounds__(256) void epilogue_fwd_vec_kernel(
         float vs = 0.f;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
-            const int c = (lane + 64 * i) * 4;
-            if (c < H) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = cache[i][e] - mean;
-                    vs += d * d;
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float d = cache[i][e] - mean;
+                vs += ok[i] ? d * d : 0.f;
             }
         }
         const float var = wave_sum(vs) / (float)H;
         rstd = 1.0f / sqrtf(var + 1e-5f);
     }
+    // ---- values
+    f32x4 yh[EPL], r[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            yh[i][e] = (cache[i][e] - mean) * rstd;
+            r[i][e] = fmaxf(yh[i][e], 0.f);
+        }
+        if (mask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[i][e] = ((mb[i] >> (8 * e)) & 0xffu) ? r[i][e] * keep_scale : 0.f;
+        }
+    }
+    // ---- stores
+    C2_VMCNT0();
     if (rstd_out && lane == 0) rstd_out[row] = rstd;
     const int64_t plane = B * ldp;  // (planes: rows ldp elements apart, the low plane B rows on)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < H) {
-            f32x4 yh, r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                yh[e] = (cache[i][e] - mean) * rstd;
-                r[e] = fmaxf(yh[e], 0.f);
-            }
-            if (yhat) *reinterpret_cast<f32x4*>(yhat + row * (int64_t)H + c) = yh;
-            if (mask) {
-                const unsigned mb = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = ((mb >> (8 * e)) & 0xffu) ? r[e] * keep_scale : 0.f;
-            }
-            store_out4(act + row * ldact + c, r);
-            if (planes) store_planes4(planes + row * ldp + c, plane, r);
+        if (ok[i]) {
+            if (yhat) *reinterpret_cast<f32x4*>(yhat + row * (int64_t)H + cc[i]) = yh[i];
+            store_out4(act + row * ldact + cc[i], r[i]);
+            if (planes) store_planes4(planes + row * ldp + cc[i], plane, r[i]);
         }
     }
 }
@@ -367,55 +412,67 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    bool ok[EPL];
+    int cc[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        ok[i] = c < H;
+        cc[i] = ok[i] ? c : 0;
+    }
+    // ---- loads
     const float es = (extra && extra_scale_dev) ? *extra_scale_dev : 1.f;
-    f32x4 cdy[EPL], cyh[EPL];
+    const float rstd = use_ln ? rstd_in[row] : 1.f;
+    f32x4 cdy[EPL], cyh[EPL], ex[EPL];
+    unsigned mb[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) cyh[i] = *reinterpret_cast<const f32x4*>(yhat + row * (int64_t)H + cc[i]);
+    slab_sums<EPL>(cdy, dA + row * ldda, cc, nslab, slab_stride);
+    if (extra) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) ex[i] = *reinterpret_cast<const f32x4*>(extra + row * ldextra + cc[i]);
+    }
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) mb[i] = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + cc[i]);
+    }
+    // ---- arithmetic
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        f32x4 d = {0.f, 0.f, 0.f, 0.f}, yh = d;
-        if (c < H) {
-            for (int s0 = 0; s0 < nslab; s0 += 4) {  // groups of four independent loads
-                f32x4 t[4];
+        f32x4 d = cdy[i];
+        if (extra) d += es * ex[i];
+        if (mask) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    t[u] = (s0 + u < nslab) ? *reinterpret_cast<const f32x4*>(dA + (s0 + u) * slab_stride + row * ldda + c)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-                d += (t[0] + t[1]) + (t[2] + t[3]);
-            }
-            if (extra) d += es * *reinterpret_cast<const f32x4*>(extra + row * ldextra + c);
-            if (mask) {
-                const unsigned mb = *reinterpret_cast<const unsigned*>(mask + row * (int64_t)H + c);
+            for (int e = 0; e < 4; ++e) d[e] = ((mb[i] >> (8 * e)) & 0xffu) ? d[e] * keep_scale : 0.f;
+        }
+        cyh[i] = sel4(ok[i], cyh[i]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = ((mb >> (8 * e)) & 0xffu) ? d[e] * keep_scale : 0.f;
-            }
-            yh = *reinterpret_cast<const f32x4*>(yhat + row * (int64_t)H + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                d[e] = yh[e] > 0.f ? d[e] : 0.f;
-                s1 += d[e];
-                s2 += d[e] * yh[e];
-            }
+        for (int e = 0; e < 4; ++e) {
+            d[e] = (ok[i] && cyh[i][e] > 0.f) ? d[e] : 0.f;
+            s1 += d[e];
+            s2 += d[e] * cyh[i][e];
         }
         cdy[i] = d;
-        cyh[i] = yh;
     }
-    float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+    float m1 = 0.f, m2 = 0.f;
     if (use_ln) {
         m1 = wave_sum(s1) / (float)H;
         m2 = wave_sum(s2) / (float)H;
-        rstd = rstd_in[row];
     }
+    f32x4 g[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[i][e] = use_ln ? (cdy[i][e] - m1 - cyh[i][e] * m2) * rstd : cdy[i][e];
+    // ---- stores
+    C2_VMCNT0();
     const int64_t plane = B * ldp;  // (planes: rows ldp elements apart, the low plane B rows on)
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < H) {
-            f32x4 g;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = use_ln ? (cdy[i][e] - m1 - cyh[i][e] * m2) * rstd : cdy[i][e];
-            store_out4(dh + row * lddh + c, g);
-            if (planes) store_planes4(planes + row * ldp + c, plane, g);
+        if (ok[i]) {
+            store_out4(dh + row * lddh + cc[i], g[i]);
+            if (planes) store_planes4(planes + row * ldp + cc[i], plane, g[i]);
         }
     }
 }

@@ -34,11 +34,15 @@ struct GemmArgs {
 
 // One 4-column piece of an output row: alpha * v + bias, as fp32 or halves.  dst_row: the row's first element (fp32 view of
 // C); col: first of the four columns; vec: the 4 columns exist and the address is aligned for one store.
-__device__ __forceinline__ void store_out4(const GemmArgs& a, float* C, int64_t row, int col, const f32x4& v, float alpha,
-                                           const float (&bv0)[4], bool vec, bool first_split = true) {
+// RS: the launch has a rank-one term, `rs` = rowscale[row] (0 on every split but the first), fetched by the CALLER before
+// its store loop.  A load inside the loop -- even one behind a branch that is never taken -- makes the compiler open every
+// iteration with s_waitcnt vmcnt(0), and on this architecture that counter also holds the stores: each 16-byte store then
+// waited for the one before it to be acknowledged by memory (16-32 round trips per wave and epilogue, ~0.25 us each).
+template <bool RS>
+__device__ __forceinline__ void store_out4t(const GemmArgs& a, float* C, int64_t row, int col, const f32x4& v, float alpha,
+                                            const float (&bv0)[4], bool vec, float rs) {
     float bv[4] = {bv0[0], bv0[1], bv0[2], bv0[3]};
-    if (a.rowscale) {
-        const float rs = first_split ? a.rowscale[row] : 0.f;
+    if (RS) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) bv[c] *= rs;
     }
@@ -67,6 +71,31 @@ __device__ __forceinline__ void store_out4(const GemmArgs& a, float* C, int64_t 
         for (int c = 0; c < 4; ++c)
             if (col + c < a.N) dst[c] = alpha * v[c] + bv[c];
     }
+}
+
+// NR 16-byte row pieces of an fp32 output, rows `step` elements apart, stored with EVERY value and address formed before
+// the first store issues.  On gfx950 a store's data and address registers count as busy until vmcnt has seen the store
+// complete: a loop that forms piece r + 1 in the registers of piece r (what the allocator does with a read - scale - store
+// loop) opens every iteration with s_waitcnt vmcnt(0) and so waits out the previous store's round trip to memory --
+// measured 0.25 us per store, 4-8 us per wave and epilogue, the whole fixed cost of a small GEMM launch.  The caller
+// guarantees (wave-uniformly) that all NR pieces exist and are aligned; pieces are alpha * v + bv (* rs[r] with RS).
+template <int NR, bool RS, typename LdsRead>
+__device__ __forceinline__ void store_rows16(float* dst, int64_t step, float alpha, const float (&bv)[4], const float* rs,
+                                             LdsRead&& piece) {
+    f32x4 o[NR];
+    float* p[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const f32x4 v = piece(r);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[r][c] = alpha * v[c] + (RS ? bv[c] * rs[r] : bv[c]);
+        p[r] = dst + r * step;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) *reinterpret_cast<f32x4*>(p[r]) = o[r];
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Block-tile edge gemm_wide.hip uses for this problem (256 or 128), or 0 when it does not take it.

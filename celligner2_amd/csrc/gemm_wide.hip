@@ -57,6 +57,10 @@ namespace C2_WIDE_NS {
 #define C2_GEMM_DBG 0
 #endif
 constexpr int dbg = C2_GEMM_DBG;
+// 0: ablation build -- every epilogue on its read - scale - store loop (A/B of store_rows16)
+#ifndef C2_EPI_BATCH
+#define C2_EPI_BATCH 1
+#endif
 
 #if C2_GEMM_DBG & 16
 __device__ unsigned long long g_clk[4];  // shader-clock cycles and 100 MHz ticks of block 0 (clock probe)
@@ -553,6 +557,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
     asm volatile("" ::: "memory");
+    if (dbg & 32) {  // (ablation: no epilogue -- one store keeps the accumulators alive)
+        if (M16) { if (acc16[0][0][0] == 123.456f) a.C[0] = 1.f; } else if (acc[0][0][0] == 123.456f) a.C[0] = 1.f;
+        return;
+    }
     const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
     float* C = a.C + (int64_t)split * a.slab_stride;
     float* wl = reinterpret_cast<float*>(smem + wave * 16384);  // [64 rows][64 cols] fp32, private to the wave
@@ -598,6 +606,29 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         if (half16) {
             // output as IEEE halves: eight columns (16 bytes) per lane, eight rows per pass -- 128-byte row segments by
             // 16-byte stores instead of the 8-byte stores the four-column walk would make of them
+            const int rowh = m0 + wm * (MI * 32) + half * 64 + (lane >> 3);
+            if (C2_EPI_BATCH && __all(col8 + 8 <= a.N && rowh + 56 < a.M)) {
+                // an interior wave tile: the eight packed pieces and their addresses first, then eight stores back to back
+                // (a store's registers are busy until vmcnt has seen it complete: see store_rows16)
+                u32x4 pk[8];
+                f16_t* p8[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rr * 8 + (lane >> 3);
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 7) * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 7) * 8 + 4);
+                    pk[rr][0] = pack2<f16_t>(alpha * v0[0] + bv8[0], alpha * v0[1] + bv8[1]);
+                    pk[rr][1] = pack2<f16_t>(alpha * v0[2] + bv8[2], alpha * v0[3] + bv8[3]);
+                    pk[rr][2] = pack2<f16_t>(alpha * v1[0] + bv8[4], alpha * v1[1] + bv8[5]);
+                    pk[rr][3] = pack2<f16_t>(alpha * v1[2] + bv8[6], alpha * v1[3] + bv8[7]);
+                    p8[rr] = reinterpret_cast<f16_t*>(C) + (int64_t)(rowh + rr * 8) * a.ldc + col8;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<u32x4*>(p8[rr]) = pk[rr];
+                __builtin_amdgcn_sched_barrier(0);
+            } else
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = rr * 8 + (lane >> 3);
@@ -614,19 +645,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
                         *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(C) + (int64_t)row * a.ldc + col8) = pk;
                     } else {
                         const float bl[4] = {bv8[0], bv8[1], bv8[2], bv8[3]}, bh[4] = {bv8[4], bv8[5], bv8[6], bv8[7]};
-                        store_out4(a, C, row, col8, v0, alpha, bl, false, split == 0);
-                        store_out4(a, C, row, col8 + 4, v1, alpha, bh, false, split == 0);
+                        store_out4t<false>(a, C, row, col8, v0, alpha, bl, false, 0.f);  // (half16: no rank-one term)
+                        store_out4t<false>(a, C, row, col8 + 4, v1, alpha, bh, false, 0.f);
                     }
                 }
             }
         } else {
+            // (two instances of the walk, chosen by a uniform branch OUTSIDE it; the rank-one factors of the one are fetched
+            // before its first store: no load inside either loop -- see store_out4t)
+            const int row0 = m0 + wm * (MI * 32) + half * 64 + (lane >> 4);
+            auto piece = [&](int rr) { return *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4); };
+            // an interior wave tile (every piece exists, aligned, fp32): all sixteen stores in flight together
+            const bool fast = C2_EPI_BATCH && !a.c_f16 && !(dbg & 64) && __all(vec_ok && row0 + 60 < a.M);
+            if (a.rowscale) {
+                float rs[16];
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int r = rr * 4 + (lane >> 4);
-                f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
-                const int row = m0 + wm * (MI * 32) + half * 64 + r;
-                if (row < a.M) {
-                    store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
+                for (int rr = 0; rr < 16; ++rr) rs[rr] = (split == 0 && row0 + rr * 4 < a.M) ? a.rowscale[row0 + rr * 4] : 0.f;
+                if (fast) store_rows16<16, true>(C + (int64_t)row0 * a.ldc + col4, 4 * a.ldc, alpha, bv, rs, piece);
+                else
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+                    if (row0 + rr * 4 < a.M) store_out4t<true>(a, C, row0 + rr * 4, col4, v, alpha, bv, vec_ok, rs[rr]);
+                }
+            } else if (fast) {
+                store_rows16<16, false>(C + (int64_t)row0 * a.ldc + col4, 4 * a.ldc, alpha, bv, nullptr, piece);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+                    if (row0 + rr * 4 < a.M && (!(dbg & 64) || v[0] == 123.456f))  // (dbg 64: the LDS trip without the stores)
+                        store_out4t<false>(a, C, row0 + rr * 4, col4, v, alpha, bv, vec_ok, 0.f);
                 }
             }
         }
@@ -926,13 +975,27 @@ __global__ __launch_bounds__(1024) void gemm_wide16_kernel(GemmArgs a, int tiles
                 for (int e = 0; e < 4; ++e)
                     wl[(ii * 16 + 4 * (lane >> 4) + e) * 64 + j * 16 + (lane & 15)] = acc16[qt * 2 + ii][j][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row0 = m0 + wm * 64 + qt * 32 + (lane >> 4);
+        auto piece = [&](int rr) { return *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4); };
+        const bool fast = C2_EPI_BATCH && !a.c_f16 && __all(vec_ok && row0 + 28 < a.M);  // (see store_rows16)
+        if (a.rowscale) {  // (no load inside either store loop: see store_out4t)
+            float rs[8];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = rr * 4 + (lane >> 4);
-            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 64 + (lane & 15) * 4);
-            const int row = m0 + wm * 64 + qt * 32 + r;
-            if (row < a.M) {
-                store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
+            for (int rr = 0; rr < 8; ++rr) rs[rr] = (split == 0 && row0 + rr * 4 < a.M) ? a.rowscale[row0 + rr * 4] : 0.f;
+            if (fast) store_rows16<8, true>(C + (int64_t)row0 * a.ldc + col4, 4 * a.ldc, alpha, bv, rs, piece);
+            else
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+                if (row0 + rr * 4 < a.M) store_out4t<true>(a, C, row0 + rr * 4, col4, v, alpha, bv, vec_ok, rs[rr]);
+            }
+        } else if (fast) {
+            store_rows16<8, false>(C + (int64_t)row0 * a.ldc + col4, 4 * a.ldc, alpha, bv, nullptr, piece);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * 4 + (lane >> 4)) * 64 + (lane & 15) * 4);
+                if (row0 + rr * 4 < a.M) store_out4t<false>(a, C, row0 + rr * 4, col4, v, alpha, bv, vec_ok, 0.f);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next quarter overwrites
@@ -1087,13 +1150,28 @@ __global__ __launch_bounds__(64 * NWX) void gemm_x3_kernel(GemmArgs a, int tiles
                 wl[r * WCOLS + j * 32 + (lane & 31)] = acc[ii][j][e];
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int NRR = MI * 32 / RPP;
+    const int row0 = m0 + wm * (MI * 32) + lane / LPR;
+    auto piece = [&](int rr) { return *reinterpret_cast<const f32x4*>(wl + (rr * RPP + lane / LPR) * WCOLS + (lane % LPR) * 4); };
+    const bool fast = C2_EPI_BATCH && !a.c_f16 && __all(vec_ok && row0 + (NRR - 1) * RPP < a.M);  // (see store_rows16)
+    if (a.rowscale) {  // (no load inside either store loop: see store_out4t)
+        float rs[NRR];
 #pragma unroll
-    for (int rr = 0; rr < MI * 32 / RPP; ++rr) {
-        const int r = rr * RPP + lane / LPR;
-        f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * WCOLS + (lane % LPR) * 4);
-        const int row = m0 + wm * (MI * 32) + r;
-        if (row < a.M) {
-            store_out4(a, C, row, col4, v, alpha, bv, vec_ok, split == 0);
+        for (int rr = 0; rr < NRR; ++rr) rs[rr] = (split == 0 && row0 + rr * RPP < a.M) ? a.rowscale[row0 + rr * RPP] : 0.f;
+        if (fast) store_rows16<NRR, true>(C + (int64_t)row0 * a.ldc + col4, (int64_t)RPP * a.ldc, alpha, bv, rs, piece);
+        else
+#pragma unroll
+        for (int rr = 0; rr < NRR; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * RPP + lane / LPR) * WCOLS + (lane % LPR) * 4);
+            if (row0 + rr * RPP < a.M) store_out4t<true>(a, C, row0 + rr * RPP, col4, v, alpha, bv, vec_ok, rs[rr]);
+        }
+    } else if (fast) {
+        store_rows16<NRR, false>(C + (int64_t)row0 * a.ldc + col4, (int64_t)RPP * a.ldc, alpha, bv, nullptr, piece);
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < NRR; ++rr) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + (rr * RPP + lane / LPR) * WCOLS + (lane % LPR) * 4);
+            if (row0 + rr * RPP < a.M) store_out4t<false>(a, C, row0 + rr * RPP, col4, v, alpha, bv, vec_ok, 0.f);
         }
     }
 }

@@ -861,18 +861,29 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) racc[e] += __shfl_xor(racc[e], o, 64);
     }
+    // (every f_i of the wave's 32 x 64 block is requested before the first store: written as load - combine - store per
+    // element the 32 elements of a lane were 32 serial round trips to memory, the wait for each load also waiting for the
+    // store before it -- on this architecture stores count in vmcnt)
     float* slab = gslabs + (int64_t)js * Bl * D;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {  // (two batches of sixteen: the kernel runs at 128 registers)
+        const int dcol = h * 32 + lo;
+        float fi[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int64_t li = i0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            const int dcol = h * 32 + lo;
-            if (li < Bl && dcol < D) {
-                const float fi = f[(row0 + li) * ldf + dcol];
-                slab[li * D + dcol] = 2.f * beta * (gacc[h][e] - racc[e] * fi);
-            }
+            const bool ok = li < Bl && dcol < D;
+            fi[e] = f[ok ? (row0 + li) * ldf + dcol : (row0 + i0) * ldf];  // (past the edge: any valid element, unused)
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) fi[e] = 2.f * beta * (gacc[h][e] - racc[e] * fi[e]);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0), where the compiler's own counter sees it: no wait between the stores
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t li = i0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (li < Bl && dcol < D) slab[li * D + dcol] = fi[e];
+        }
+    }
     lacc = wave_sum(lacc);
     if (lane == 0) loss_partials[(int64_t)js * nit + it] = beta * lacc;
 }
