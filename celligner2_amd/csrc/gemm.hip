@@ -282,19 +282,36 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
         __syncthreads();
     }
 
+    // Epilogue: every load (alpha, the two bias columns, the rank-one factors of the lane's 32 rows) before the first
+    // store, and an s_waitcnt the compiler's counter sees: a load inside the store loop -- even behind a branch never taken
+    // -- made each of a lane's 64 stores wait for the one before it (stores count in vmcnt on gfx950).
     const float alpha = a.alpha_dev ? *a.alpha_dev : 1.f;
     float* C = a.C + (int64_t)split * a.slab_stride;
+    float bvj[2], rs[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        bvj[j] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+    }
+    const bool has_rs = a.rowscale != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            rs[i][e] = (has_rs && split == 0 && row < a.M) ? a.rowscale[row] : 0.f;
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            const float bv = (a.bias && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (row < a.M && col < a.N) {
-                    const float add = a.rowscale ? (split == 0 ? bv * a.rowscale[row] : 0.f) : bv;
+                    const float add = has_rs ? bvj[j] * rs[i][e] : bvj[j];
                     if (a.c_f16) reinterpret_cast<f16_t*>(C)[(int64_t)row * a.ldc + col] = (f16_t)(alpha * acc[i][j][e] + add);
                     else C[(int64_t)row * a.ldc + col] = alpha * acc[i][j][e] + add;
                 }

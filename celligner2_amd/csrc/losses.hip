@@ -527,30 +527,59 @@ __global__ __launch_bounds__(NT) void nb_rowreg_kernel(NbArgs a) {
         const int64_t Gp = nb_tab_ld(G);
         float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * G;
         const bool first = !((flushed >> pat) & 1);
+        // In groups of up to five chunks: every load of a group (three table rows, the partial written so far) is issued
+        // before its first use and every store after the last load -- chunk by chunk each load waited for the store of the
+        // chunk before it (stores count in vmcnt on this architecture): ten serial round trips to memory per flush.
+        // Chunks past the row's end read chunk 0 (a valid address) and store nothing.
+        constexpr int GRP = NV < 5 ? NV : 5;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = 4 * (tid + NT * i);
-            if (c < Gi) {
-                const f32x4 th4 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 0) * Gp + c);
-                const f32x4 k14 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 1) * Gp + c);
-                const f32x4 k24 = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 2) * Gp + c);
+        for (int i0 = 0; i0 < NV; i0 += GRP) {
+            f32x4 th4[GRP], k14[GRP], k24[GRP], old[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                const int c = 4 * (tid + NT * (i0 + j));
+                const int cc = (i0 + j < NV && c < Gi) ? c : 0;
+                th4[j] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 0) * Gp + cc);
+                k14[j] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 1) * Gp + cc);
+                k24[j] = *reinterpret_cast<const f32x4*>(a.tab + (int64_t)(pat * 3 + 2) * Gp + cc);
+            }
+            if (REGT && !first) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int c = 4 * (tid + NT * (i0 + j));
+                    old[j] = *reinterpret_cast<const f32x4*>(dst + ((i0 + j < NV && c < Gi) ? c : 0));
+                }
+            }
+            f32x4 acc[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                if (i0 + j >= NV) continue;
+                const int i = i0 + j;
+                const int c = 4 * (tid + NT * i);
                 f32x4 n4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) n4[e] = (float)((kept[i] >> (8 * e)) & 0xffu);
-                const f32x4 add = (-a.inv_B) * (th4 * k24 * n4);
+                const f32x4 add = (-a.inv_B) * (th4[j] * k24[j] * n4);
                 if (REGT) {  // every thread owns its genes: no LDS, no barrier
-                    f32x4 acc = dreg[i] + add;
-                    if (!first) acc += *reinterpret_cast<const f32x4*>(dst + c);
-                    *reinterpret_cast<f32x4*>(dst + c) = acc;
+                    acc[j] = dreg[i] + add;
+                    if (!first) acc[j] += old[j];
                     dreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    f32x4 acc = *reinterpret_cast<f32x4*>(dacc + c);
-                    acc += add;
-                    *reinterpret_cast<f32x4*>(dacc + c) = acc;
+                } else if (c < Gi) {
+                    f32x4 t = *reinterpret_cast<f32x4*>(dacc + c);
+                    t += add;
+                    *reinterpret_cast<f32x4*>(dacc + c) = t;
                 }
-                loss_acc += (k14[0] * n4[0] + k14[1] * n4[1]) + (k14[2] * n4[2] + k14[3] * n4[3]);
+                if (c < Gi) loss_acc += (k14[j][0] * n4[0] + k14[j][1] * n4[1]) + (k14[j][2] * n4[2] + k14[j][3] * n4[3]);
+                kept[i] = 0u;
             }
-            kept[i] = 0u;
+            if (REGT) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0) where the compiler's counter sees it
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const int c = 4 * (tid + NT * (i0 + j));
+                    if (i0 + j < NV && c < Gi) *reinterpret_cast<f32x4*>(dst + c) = acc[j];
+                }
+            }
         }
         rows_kept = 0;
         flushed |= 1 << pat;
