@@ -518,17 +518,38 @@ __global__ __launch_bounds__(512) void bias_cond_stage1(const TI* __restrict__ d
     for (int j = 0; j < CC; ++j) acc[j][0] = acc[j][1] = 0.f;
     if (col < H) {
         const bool two = col + 1 < H;
-        for (int64_t b = b0 + ry; b < b1; b += RYN) {
-            float v0, v1;
+        // four rows per trip, every load of the trip (the rows, their condition values -- unconditionally: a column past the
+        // last re-reads the last and counts as 0) issued before the first use: row by row, with the condition load behind a
+        // branch, each row was a serial round trip to memory
+        auto row = [&](int64_t b, float& v0, float& v1, float (&cj)[CC > 0 ? CC : 1]) {
             ld2<TI>(dh + b * lddh + col, two, v0, v1);
+#pragma unroll
+            for (int j = 0; j < CC; ++j) {
+                const float c = (float)cond[b * C + min(c0 + j, C - 1)];
+                cj[j] = (c0 + j < C) ? c : 0.f;
+            }
+        };
+        auto use = [&](float v0, float v1, const float (&cj)[CC > 0 ? CC : 1]) {
             a0[0] += v0;
             a0[1] += v1;
 #pragma unroll
             for (int j = 0; j < CC; ++j) {
-                const float cj = (c0 + j < C) ? (float)cond[b * C + c0 + j] : 0.f;
-                acc[j][0] += v0 * cj;
-                acc[j][1] += v1 * cj;
+                acc[j][0] += v0 * cj[j];
+                acc[j][1] += v1 * cj[j];
             }
+        };
+        int64_t b = b0 + ry;
+        for (; b + 3 * RYN < b1; b += 4 * RYN) {
+            float v0[4], v1[4], cj[4][CC > 0 ? CC : 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row(b + u * RYN, v0[u], v1[u], cj[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) use(v0[u], v1[u], cj[u]);
+        }
+        for (; b < b1; b += RYN) {
+            float v0, v1, cj[CC > 0 ? CC : 1];
+            row(b, v0, v1, cj);
+            use(v0, v1, cj);
         }
     }
     red[ry][0][2 * cx] = a0[0];
@@ -579,7 +600,9 @@ __global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh
 #pragma unroll
         for (int e = 0; e < W; ++e) acc[k][e] = 0.f;
     if (col < H) {
-        auto add = [&](const u32x4& v, int64_t b) {
+        // (the rows' condition values are handed in, fetched by the caller together with the rows: a load inside this
+        // accumulation made each of the eight rows in flight wait for its own round trip to memory)
+        auto add = [&](const u32x4& v, const float (&cj)[CC > 0 ? CC : 1]) {
             float x[W];
             if constexpr (sizeof(TI) == 2) {
 #pragma unroll
@@ -598,20 +621,34 @@ __global__ __launch_bounds__(256) void bias_stage1_vec(const TI* __restrict__ dh
             for (int e = 0; e < W; ++e) acc[0][e] += x[e];
 #pragma unroll
             for (int j = 0; j < CC; ++j) {
-                const float cj = (c0 + j < C) ? (float)cond[b * C + c0 + j] : 0.f;
 #pragma unroll
-                for (int e = 0; e < W; ++e) acc[1 + j][e] += x[e] * cj;
+                for (int e = 0; e < W; ++e) acc[1 + j][e] += x[e] * cj[j];
+            }
+        };
+        auto conds = [&](int64_t b, float (&cj)[CC > 0 ? CC : 1]) {
+#pragma unroll
+            for (int j = 0; j < CC; ++j) {  // (no branch around the load: a column past the last re-reads the last, then 0)
+                const float c = (float)cond[b * C + min(c0 + j, C - 1)];
+                cj[j] = (c0 + j < C) ? c : 0.f;
             }
         };
         int64_t b = b0 + ry;
         for (; b + 28 < b1; b += 32) {
             u32x4 v[8];
+            float cj[8][CC > 0 ? CC : 1];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(dh + (b + 4 * u) * lddh + col);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) add(v[u], b + 4 * u);
+            for (int u = 0; u < 8; ++u) conds(b + 4 * u, cj[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(v[u], cj[u]);
         }
-        for (; b < b1; b += 4) add(*reinterpret_cast<const u32x4*>(dh + b * lddh + col), b);
+        for (; b < b1; b += 4) {
+            float cj[CC > 0 ? CC : 1];
+            const u32x4 v = *reinterpret_cast<const u32x4*>(dh + b * lddh + col);
+            conds(b, cj);
+            add(v, cj);
+        }
     }
 #pragma unroll
     for (int k = 0; k <= CC; ++k)
