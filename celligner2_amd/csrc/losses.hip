@@ -922,6 +922,9 @@ __global__ __launch_bounds__(256) void nb_dtheta_stage1(const float* __restrict_
     const int per = (ngroups + kDthSlices - 1) / kDthSlices;
     const int g0 = sl * per, g1 = min(ngroups, g0 + per);
     if (g >= G) return;
+    // (the load stays behind the flag's branch: most workgroups see one or two of the three patterns, and loading the
+    // unflagged rows as well -- four in flight, dropped by a select -- was measured slower, 16 -> 20 us: more bytes than
+    // the serial round trips cost)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         float s = 0.f;
@@ -1252,12 +1255,22 @@ __global__ __launch_bounds__(NT) void zinb_rowreg_kernel(NbArgs a, ZinbExtra z) 
     auto flush = [&](int pat) {  // every thread owns its genes: no barrier
         float* dst = a.part_dt + ((int64_t)blockIdx.x * 3 + pat) * a.G;
         const bool first = !((flushed >> pat) & 1);
+        // (every load of the partial written so far before the first store: see the NB kernel's flush)
+        f32x4 old[NV];
+        if (!first) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = 4 * (tid + NT * i);
+                old[i] = *reinterpret_cast<const f32x4*>(dst + (c < Gi ? c : 0));
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0) where the compiler's counter sees it
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * (tid + NT * i);
             if (c < Gi) {
                 f32x4 v = acc[i * NT + tid];
-                if (!first) v += *reinterpret_cast<const f32x4*>(dst + c);
+                if (!first) v += old[i];
                 *reinterpret_cast<f32x4*>(dst + c) = v;
                 acc[i * NT + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
