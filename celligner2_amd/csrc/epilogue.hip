@@ -790,7 +790,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         // nothing per gene: the consumers read the resident rows themselves
     } else if (vec_ok) {
         const int64_t gv = Gw >> 2;
-        auto emit = [&](int64_t c, const f32x4& v, unsigned gm) {
+        // The chunk's four centre values are fetched by the CALLER, with the chunk (a load in here, after the stores of
+        // the chunk before, made every chunk wait for those stores: they count in vmcnt on this architecture).  center has
+        // G entries: the chunk that holds the pad columns is handed the last four, cv = center[G-4 .. G), and picks its own.
+        auto center4 = [&](int64_t c) {
+            f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+            if (center) {  // (G >= 4 on this path; 4-byte alignment is all a global 16-byte load needs)
+                const int64_t at = min(c * 4, G - 4);
+                cv = f32x4{center[at], center[at + 1], center[at + 2], center[at + 3]};
+            }
+            return cv;
+        };
+        auto emit = [&](int64_t c, const f32x4& v, unsigned gm, const f32x4& cv) {
             if (xd) reinterpret_cast<f32x4*>(xd)[c] = v;
             if (xin_out || xin2_out) {
                 f32x4 t;
@@ -798,11 +809,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
                 for (int e = 0; e < 4; ++e) t[e] = apply_log ? log1p_count(v[e]) : v[e];
                 if (center) {
                     if (c * 4 + 4 <= G) {
-                        t -= reinterpret_cast<const f32x4*>(center)[c];
-                    } else {  // the chunk that holds the pad columns: center has G entries
+                        t -= cv;
+                    } else {  // the chunk that holds the pad columns: column c*4+e < G is entry e + s of the last four
+                        const int sft = (int)(c * 4 - (G - 4));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c * 4 + e < G) t[e] -= center[c * 4 + e];
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = e + sft;
+                            const float ce = k == 0 ? cv[0] : (k == 1 ? cv[1] : (k == 2 ? cv[2] : cv[3]));
+                            if (c * 4 + e < G) t[e] -= ce;
+                        }
                     }
                 }
                 if (xin_out) {
@@ -847,7 +862,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         const int64_t cbeg = min(gv0, (int64_t)part * per), cend = min(gv0, cbeg + per);
         int64_t c = cbeg + threadIdx.x;
         for (; c + 768 < cend; c += 1024) {  // four independent 16-byte loads in flight per thread
-            f32x4 v[4];
+            f32x4 v[4], cv[4];
             unsigned gm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(xs)[c + 256 * u];
@@ -856,9 +871,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
                 for (int u = 0; u < 4; ++u) gm[u] = gs[c + 256 * u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) emit(c + 256 * u, v[u], gm[u]);
+            for (int u = 0; u < 4; ++u) cv[u] = center4(c + 256 * u);
+            C2_VMCNT0();  // (one wait the compiler's counter sees, ahead of the stores' branches: none inside them)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(c + 256 * u, v[u], gm[u], cv[u]);
         }
-        for (; c < cend; c += 256) emit(c, reinterpret_cast<const f32x4*>(xs)[c], copy_good ? gs[c] : 0u);
+        for (; c < cend; c += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(xs)[c];
+            const unsigned gm = copy_good ? gs[c] : 0u;
+            const f32x4 cv = center4(c);
+            C2_VMCNT0();
+            emit(c, v, gm, cv);
+        }
     } else {
         const int64_t per = ((G + nparts - 1) / nparts + 255) / 256 * 256;
         const int64_t cbeg = min(G, (int64_t)part * per), cend = min(G, cbeg + per);
