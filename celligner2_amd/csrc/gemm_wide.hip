@@ -278,6 +278,50 @@ __device__ __forceinline__ void compute_tile16(const char* tA, const char* tB, i
     mma16_group(ahi, b1, acc, 4, piece, 3);
 }
 
+// The same K-tile rotated by one MFMA group (C2_WIDE_ROT, steady-state loop only): right after a tile's barrier all
+// eight waves ask the LDS for their first fragments at once, and nothing they could multiply has arrived -- so the LAST
+// group of the previous tile (its operands `ahi`, `b1` are in registers since before the barrier) is multiplied there,
+// under that burst of reads.  Same accumulation order per accumulator, so bit-identical results; the caller zero-fills
+// `ahi` / `b1` before the first tile and multiplies the group left over after the last one (flush_tile16).
+template <bool A_RC, bool B_RC, int BX, typename F>
+__device__ __forceinline__ void compute_tile16_rot(const char* tA, const char* tB, int wm, int wn, int lane,
+                                                   f32x4 (&acc)[8][4], F&& piece, bf16x8 (&ahi)[4], bf16x8 (&b1)[4]) {
+    bf16x8 b0[4], alo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = read_frag16<B_RC, BX>(tB, wn * 64 + j * 16, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) alo[i] = read_frag16<A_RC, BX>(tA, wm * 128 + i * 16, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);  // the reads are on their way before the held group starts
+    piece(0);  // (behind the group's first eight MFMAs instead: measured 0.3 % slower per step)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // a row of the held group, then the read that refills its A fragment: three of the four
+                                   // reads the next group waits for (every LDS wait here is a full drain) are issued early
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + i][j] = C2_MFMA_16x16x32(ahi[i], b1[j], acc[4 + i][j]);
+        ahi[i] = read_frag16<A_RC, BX>(tA, wm * 128 + 64 + i * 16, 0, lane);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    mma16_group(alo, b0, acc, 0, piece, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = read_frag16<B_RC, BX>(tB, wn * 64 + j * 16, 1, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) alo[i] = read_frag16<A_RC, BX>(tA, wm * 128 + i * 16, 1, lane);
+    mma16_group(ahi, b0, acc, 4, piece, 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ahi[i] = read_frag16<A_RC, BX>(tA, wm * 128 + 64 + i * 16, 1, lane);
+    mma16_group(alo, b1, acc, 0, piece, 3);
+}
+__device__ __forceinline__ void flush_tile16(f32x4 (&acc)[8][4], const bf16x8 (&ahi)[4], const bf16x8 (&b1)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + i][j] = C2_MFMA_16x16x32(ahi[i], b1[j], acc[4 + i][j]);
+}
+#ifndef C2_WIDE_ROT
+#define C2_WIDE_ROT 1
+#endif
+
 // s_waitcnt vmcnt(4 * c): all but the c newest operand-tile loads (4 DMA instructions per wave each) have landed
 __device__ __forceinline__ void wait_loads(int c) {
     switch (c) {
@@ -408,6 +452,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
 
+    constexpr bool ROT = M16 && C2_WIDE_ROT;
+    bf16x8 held_a[ROT ? 4 : 1], held_b[ROT ? 4 : 1];  // (compute_tile16_rot: the previous tile's last MFMA group)
+    if (ROT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            held_a[i] = __builtin_bit_cast(bf16x8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+            held_b[i] = __builtin_bit_cast(bf16x8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+        }
+    }
+
     // ---- issue state: the next A tile and the next B tile to stage (segment, K-tile inside it, source pointer)
     const int nseg = a.A_lo ? 3 : 1;
     int segA = 0, tA = 0, segB = 0, tB = 0;
@@ -503,7 +557,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
             if (p == 3 && !(dbg & 4)) stage_dma<2, 4>(pA, voa, d4, wave_u);
         };
         if (!(dbg & 2)) {
-            if constexpr (M16)
+            if constexpr (ROT)
+                compute_tile16_rot<A_RC, B_RC, BX>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane,
+                                                   acc16, piece, held_a, held_b);
+            else if constexpr (M16)
                 compute_tile16<A_RC, B_RC, BX>(smem + sa * TILE_BYTES, smem + slot_of(1) * TILE_BYTES, wm, wn, lane, acc16,
                                                piece);
             else
@@ -515,6 +572,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_wide_kernel(GemmArgs a, int tile
         advB();
         advA();
         sa = slot_of(2);
+    }
+    if constexpr (ROT) {
+        if (!(dbg & 2)) flush_tile16(acc16, held_a, held_b);  // the last steady-state tile's held group (zeros if there was none)
     }
     // the rest: tails, segment ends, drain
     for (; T < nt; ++T) {
