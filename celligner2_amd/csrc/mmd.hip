@@ -186,11 +186,11 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
     __shared__ int s_keypart[MAXP];  // key -> partition id
     __shared__ int s_cnt[MAXP];      // rows per partition
     __shared__ int s_bad, s_nparts;
-    __shared__ float s_wt[MAXP * MAXP];
+    constexpr int KCACHE = 32768;  // keys of the rows after the first 4096 (one byte each), so that `cond` is walked once
+    __shared__ unsigned char s_key[KCACHE];
     const int tid = threadIdx.x;
     if (tid < MAXP) { s_keycnt[tid] = 0; s_cnt[tid] = 0; s_keypart[tid] = 0; }
     if (tid == 0) { s_bad = 0; s_nparts = 0; }
-    for (int i = tid; i < MAXP * MAXP; i += 1024) s_wt[i] = 0.f;
     __syncthreads();
     int bad = 0;
     auto make_key = [&](int64_t r) {
@@ -202,10 +202,7 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
         }
         return k;
     };
-    for (int64_t r0 = 0; r0 < B; r0 += 1024) {
-        const int64_t r = r0 + tid;
-        const int k = r < B ? make_key(r) : -1;
-        // one LDS atomic per wave and key present in it (leader = lowest lane holding the key)
+    auto count_key = [&](int k) {  // one LDS atomic per wave and key present in it (leader = lowest lane holding the key)
         unsigned long long todo = __ballot(k >= 0);
         while (todo) {
             const int lead = __ffsll((long long)todo) - 1;
@@ -213,6 +210,33 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
             const unsigned long long same = __ballot(k == kl);
             if ((tid & 63) == lead) atomicAdd(&s_keycnt[kl], __popcll(same));
             todo &= ~same;
+        }
+    };
+    // The kernel is one block and a chain of latencies (it runs ahead of the MMD in every step): the keys of the first
+    // 4096 rows stay in registers -- their loads issued together, rows past the end re-reading the last row, and no second
+    // walk over `cond` where part_id is written --, and the weight table is written by 4096 entries in parallel below.
+    constexpr int KR = 4;
+    auto keys_of = [&](int64_t r0, int (&k)[KR]) {  // rows r0 + q * 1024 + tid, q < KR
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            const int64_t r = r0 + (int64_t)q * 1024 + tid;
+            const int key = make_key(min(r, B - 1));
+            k[q] = r < B ? key : -1;
+        }
+    };
+    int kreg[KR];
+    keys_of(0, kreg);
+#pragma unroll
+    for (int q = 0; q < KR; ++q)
+        if ((int64_t)q * 1024 < B) count_key(kreg[q]);
+    for (int64_t r0 = (int64_t)KR * 1024; r0 < B; r0 += (int64_t)KR * 1024) {  // (larger batches: the same, a batch at a time)
+        int k[KR];
+        keys_of(r0, k);
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            const int64_t c = r0 + (int64_t)q * 1024 + tid - (int64_t)KR * 1024;
+            if (k[q] >= 0 && c < KCACHE) s_key[c] = (unsigned char)k[q];  // (read back by the thread that wrote it)
+            if (r0 + (int64_t)q * 1024 < B) count_key(k[q]);
         }
     }
     if (bad) s_bad = 1;
@@ -241,37 +265,61 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
         if (tid == 0) s_nparts = np;
     }
     __syncthreads();
-    for (int64_t r = tid; r < B; r += 1024) part_id[r] = s_keypart[make_key(r)];
-    if (tid == 0) {
-        const int np = s_nparts;
-        auto add_pair = [&](int i, int j) {
-            const float ni = (float)s_cnt[i], nj = (float)s_cnt[j];
-            s_wt[i * MAXP + i] += 1.f / (ni * ni);
-            s_wt[j * MAXP + j] += 1.f / (nj * nj);
-            s_wt[i * MAXP + j] -= 1.f / (ni * nj);
-            s_wt[j * MAXP + i] -= 1.f / (ni * nj);
-        };
-        if (boundary >= 0) {  // losses.py:232-238
-            for (int i = 0; i < boundary; ++i)
-                for (int j = boundary; j < n_conditions; ++j) {
-                    if (i >= np || j >= np) { s_bad = 1; continue; }  // IndexError in the reference
-                    if (s_cnt[i] < 2 || s_cnt[j] < 2) continue;
-                    add_pair(i, j);
+#pragma unroll
+    for (int q = 0; q < KR; ++q)
+        if (kreg[q] >= 0) part_id[(int64_t)q * 1024 + tid] = s_keypart[kreg[q]];
+    for (int64_t r0 = (int64_t)KR * 1024; r0 < B; r0 += (int64_t)KR * 1024) {
+        int k[KR], pid[KR];
+        if (r0 <= KCACHE) {  // rows r0 .. r0 + 4095 are entries r0 - 4096 .. r0 - 1 of the key cache (block-uniform)
+#pragma unroll
+            for (int q = 0; q < KR; ++q) {
+                const int64_t r = r0 + (int64_t)q * 1024 + tid;
+                k[q] = r < B ? (int)s_key[r - (int64_t)KR * 1024] : -1;
+            }
+        } else {
+            keys_of(r0, k);
+        }
+#pragma unroll
+        for (int q = 0; q < KR; ++q) pid[q] = s_keypart[max(k[q], 0)];
+#pragma unroll
+        for (int q = 0; q < KR; ++q)
+            if (k[q] >= 0) part_id[r0 + (int64_t)q * 1024 + tid] = pid[q];
+    }
+    // Pair weights.  The reference walks the partition pairs once (losses.py:232-238 with a boundary, :240-248 without)
+    // and adds 1/ni^2, 1/nj^2 to the two diagonal entries and -1/(ni nj) to the two off-diagonal ones; here entry (x, y)
+    // decides for itself whether that walk visits the pair {x, y}, and a diagonal entry adds its 1/nx^2 once per visited
+    // partner, in sequence like the walk does (equal terms: their order does not matter, their count does).
+    const int np = s_nparts;
+    const bool bnd = boundary >= 0;
+    auto visited = [&](int x, int y) {  // x != y
+        if (bnd) {
+            const int lo = min(x, y), hi = max(x, y);
+            return lo < boundary && hi >= boundary && hi < n_conditions && hi < np && s_cnt[lo] >= 2 && s_cnt[hi] >= 2;
+        }
+        return x < np && y < np && (main_col < 0 || min(x, y) == 0);
+    };
+#pragma unroll
+    for (int q = 0; q < MAXP * MAXP / 1024; ++q) {
+        const int e = tid + 1024 * q, x = e / MAXP, y = e % MAXP;
+        float w = 0.f;
+        if (x < np && y < np) {
+            const float nx = (float)s_cnt[x];
+            if (x != y) {
+                if (visited(x, y)) {
+                    // (the walk computes 1/(ni*nj) with i the loop's outer index: the smaller one with a boundary, the
+                    // larger one without -- the product commutes, the bits are the same)
+                    w = 0.f - 1.f / (nx * (float)s_cnt[y]);
                 }
-        } else {  // losses.py:240-248
-            for (int i = 0; i < np; ++i) {
-                if (s_cnt[i] < 1) continue;
-                for (int j = 0; j < i; ++j) {
-                    if (s_cnt[j] < 1) continue;
-                    if (main_col >= 0 && j != 0) continue;
-                    add_pair(i, j);
-                }
+            } else {
+                const float t = 1.f / (nx * nx);
+                for (int o = 0; o < np; ++o)
+                    if (o != x && visited(x, o)) w += t;
             }
         }
-        if (s_bad) *status = 2;
+        wt[e] = w;
     }
-    __syncthreads();
-    for (int i = tid; i < MAXP * MAXP; i += 1024) wt[i] = s_wt[i];
+    // with a boundary every (i < boundary, boundary <= j < n_conditions) must name a partition: IndexError in the reference
+    if (tid == 0 && (s_bad || (bnd && boundary > 0 && n_conditions > boundary && n_conditions > np))) *status = 2;
 }
 
 // ---------------------------------------------------------------------------------------------------------

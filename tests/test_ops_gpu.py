@@ -540,6 +540,45 @@ def test_classifier_loss(P):
     assert (ty.cpu().numpy() == np.where(y == -1, 0, y)).all(), "classes must be mutated in place like the reference"
 
 
+@pytest.mark.parametrize("B,C,main,boundary", [(40000, 3, None, None), (40000, 4, 1, None), (9000, 4, None, 2),
+                                               (37000, 6, 0, None)])
+def test_partition_of_a_large_batch(B, C, main, boundary):
+    """The table-form partition kernel keeps the keys of its first 4096 rows in registers, those of the next 32 768 in LDS
+    and walks the condition matrix a second time only beyond that: batches that reach every one of the three, partition
+    ids against the oracle's partition, the pair-weight table bit for bit against the reference's walk over the partition
+    pairs (losses.py:232-248) in fp32."""
+    ops = _ops()
+    rng = np.random.default_rng(B + C)
+    cond = np.zeros((B, C), np.int64)
+    lab = rng.integers(0, C, B)
+    lab[:C] = np.arange(C)
+    cond[np.arange(B), lab] = 1
+    parts = orc.partition_index(cond, main)
+    part_id = torch.empty(B, device=DEV, dtype=torch.int32)
+    wt = torch.empty(64 * 64, device=DEV)
+    ws_p = torch.empty(int(ops.lib.c2_partition_ws(B)), device=DEV, dtype=torch.uint8)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    ops.partition(T(cond), C, main, boundary, part_id, wt, ws_p, status)
+    assert status.item() == 0
+    pid = part_id.cpu().numpy()
+    want_pid = np.empty(B, np.int32)
+    for k, idx in enumerate(parts):
+        want_pid[idx] = k
+    assert (pid == want_pid).all()
+    n = [np.float32(len(idx)) for idx in parts]
+    w = np.zeros((64, 64), np.float32)
+
+    def add_pair(i, j):
+        w[i, i] += np.float32(1) / (n[i] * n[i])
+        w[j, j] += np.float32(1) / (n[j] * n[j])
+        w[i, j] -= np.float32(1) / (n[i] * n[j])
+        w[j, i] -= np.float32(1) / (n[i] * n[j])
+
+    for i, j in orc.mmd_pairs(len(parts), [len(idx) for idx in parts], C, boundary, main is not None):
+        add_pair(i, j)
+    assert (wt.cpu().numpy().reshape(64, 64) == w).all()
+
+
 @pytest.mark.parametrize("B,D,C,main,boundary,multi", [(64, 10, 3, None, None, False), (200, 64, 5, 1, None, False),
                                                        (96, 5, 4, None, 2, True), (150, 100, 2, None, None, False),
                                                        (33, 16, 3, 0, None, True),
