@@ -1205,18 +1205,28 @@ __global__ __launch_bounds__(256) void gemv_bias_kernel(const float* __restrict_
         const int64_t kv = K >> 2;
         const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
         const f32x4* c4 = reinterpret_cast<const f32x4*>(c);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        int64_t i = threadIdx.x;
-        for (; i + 768 < kv; i += 1024) {  // four independent 16-byte loads of the row in flight per thread
-            const f32x4 w0 = __builtin_nontemporal_load(w4 + i), w1 = __builtin_nontemporal_load(w4 + i + 256),
-                        w2 = __builtin_nontemporal_load(w4 + i + 512), w3 = __builtin_nontemporal_load(w4 + i + 768);
-            a0 += w0 * c4[i];
-            a1 += w1 * c4[i + 256];
-            a2 += w2 * c4[i + 512];
-            a3 += w3 * c4[i + 768];
+        // ten 16-byte loads of the row (and ten of c) in flight per thread and batch, every one issued before the first is
+        // used; chunks past the row's end re-read its last chunk and count as zero (a load behind a branch is waited for
+        // inside the branch: the remainder loop of the four-loads form was three more dependent trips to memory per row)
+        constexpr int NB = 10;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int64_t i0 = 0; i0 < kv; i0 += 256 * NB) {
+            f32x4 wv[NB], cv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int64_t i = min(i0 + 256 * u + (int64_t)threadIdx.x, kv - 1);
+                wv[u] = __builtin_nontemporal_load(w4 + i);
+                cv[u] = c4[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler sinks each load to its use: one pair in flight)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float keep = (i0 + 256 * u + (int64_t)threadIdx.x < kv) ? 1.f : 0.f;
+                if (u & 1) a1 += keep * (wv[u] * cv[u]);
+                else a0 += keep * (wv[u] * cv[u]);
+            }
         }
-        for (; i < kv; i += 256) a0 += w4[i] * c4[i];
-        const f32x4 acc = (a0 + a1) + (a2 + a3);
+        const f32x4 acc = a0 + a1;
         a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     } else {
         // rows that start on 4 bytes only (a gene count that is not a multiple of 4): eight independent loads in flight
