@@ -938,6 +938,55 @@ __global__ __launch_bounds__(256) void nb_dtheta_stage1(const float* __restrict_
         part2[((int64_t)sl * 4 + 3) * G + g] = s;
     }
 }
+// The same on 16-byte accesses (G a multiple of 4, aligned partials; at most 8 workgroups per slice: ngroups <= 256).  Every
+// load of a thread -- up to eight workgroup partials of each of the four planes -- is issued before the first is used.  A
+// partial whose flag is down is not left out by a branch (the load behind it would be waited for inside it: one round
+// trip to memory per partial, which is what held the scalar form at 3 TB/s) and not loaded either (more bytes than it
+// saves, see above): its load re-reads a flagged partial of the same slice, which is in flight or in the cache, and a
+// select drops the value.  Same order of additions as the scalar form.
+__global__ __launch_bounds__(256) void nb_dtheta_stage1_v4(const float* __restrict__ part_dt, const int* __restrict__ part_flag,
+                                                           int ngroups, int64_t G, float* __restrict__ part2,
+                                                           const float* __restrict__ part_db) {
+    constexpr int PER = 8;
+    const int64_t g = (blockIdx.x * 256ll + threadIdx.x) * 4;
+    const int sl = blockIdx.y;
+    const int per = (ngroups + kDthSlices - 1) / kDthSlices;  // <= PER
+    const int g0 = sl * per, g1 = min(ngroups, g0 + per);
+    if (g >= G) return;
+    bool on[4][PER];
+    f32x4 v[4][PER];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (p == 3 && !part_db) break;
+        int any = min(g0, ngroups - 1);  // (no flagged partial in the slice: one partial's chunk is read eight times and dropped)
+#pragma unroll
+        for (int u = PER - 1; u >= 0; --u) {
+            const int grp = g0 + u;
+            on[p][u] = grp < g1 && (p == 3 || part_flag[min(grp, ngroups - 1) * 3 + p] != 0);
+            if (on[p][u]) any = grp;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int grp = on[p][u] ? g0 + u : any;
+            const float* src = p == 3 ? part_db + (int64_t)grp * G : part_dt + ((int64_t)grp * 3 + p) * G;
+            v[p][u] = *reinterpret_cast<const f32x4*>(src + g);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 s[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        s[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p == 3 && !part_db) break;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) s[p] = on[p][u] ? s[p] + v[p][u] : s[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (p == 3 && !part_db) break;
+        *reinterpret_cast<f32x4*>(part2 + ((int64_t)sl * 4 + p) * G + g) = s[p];
+    }
+}
 // column sums of dlogits where the loss kernel did not form them: slice sl of the rows into the fourth plane of part2
 template <typename TD>
 __global__ __launch_bounds__(256) void nb_colsum_kernel(const TD* __restrict__ d, int64_t ld, int64_t B, int64_t G,
@@ -995,24 +1044,47 @@ __global__ __launch_bounds__(256) void nb_dtheta_direct(const float* __restrict_
     }
     if (db) db[g] = s[3];
 }
+// stage 2: 64 genes x the four planes per block (a plane per wave), the 32 slice partials of a (gene, plane) requested
+// together and added in slice order; the planes meet in LDS.  (One thread per gene walking 4 x 32 partials eight at a time
+// was sixteen dependent trips to memory on 75 blocks: 7.5 us for 10 MB.)
 __global__ __launch_bounds__(256) void nb_dtheta_stage2(const float* __restrict__ part2, int64_t G, int C,
                                                         float* __restrict__ dtheta, float* __restrict__ db /*or NULL*/) {
-    const int64_t g = blockIdx.x * 256ll + threadIdx.x;
-    if (g >= G) return;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[4][64];
+    const int lx = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int64_t g = blockIdx.x * 64ll + lx;
+    float s = 0.f;
+    if (g < G && (p < 3 || db)) {
+        float v[kDthSlices];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p == 3 && !db) break;
-#pragma unroll 8
-        for (int sl = 0; sl < kDthSlices; ++sl) s[p] += part2[((int64_t)sl * 4 + p) * G + g];
+        for (int sl = 0; sl < kDthSlices; ++sl) v[sl] = part2[((int64_t)sl * 4 + p) * G + g];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < kDthSlices; ++sl) s += v[sl];
     }
+    red[p][lx] = s;
+    __syncthreads();
+    if (p != 0 || g >= G) return;
+    const float s0 = red[0][lx], s1 = red[1][lx], s2 = red[2][lx];
     for (int j = 0; j < C; ++j) {
         float v = 0.f;
-        if (j == 0) v = s[0] + s[2];
-        if (j == 1) v = s[1] + s[2];
+        if (j == 0) v = s0 + s2;
+        if (j == 1) v = s1 + s2;
         dtheta[g * C + j] = v;
     }
-    if (db) db[g] = s[3];
+    if (db) db[g] = red[3][lx];
+}
+
+static void launch_dtheta_stage1(const float* part_dt, const int* part_flag, int ngroups, int64_t G, float* part2,
+                                 const float* part_db, hipStream_t st) {
+    const bool v4 = (G & 3) == 0 && ngroups <= 8 * kDthSlices &&
+                    ((reinterpret_cast<uintptr_t>(part_dt) | reinterpret_cast<uintptr_t>(part2) |
+                      reinterpret_cast<uintptr_t>(part_db)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(nb_dtheta_stage1_v4, dim3((unsigned)((G / 4 + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt,
+                           part_flag, ngroups, G, part2, part_db);
+    else
+        hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt,
+                           part_flag, ngroups, G, part2, part_db);
 }
 
 // Row constant of the NB log-likelihood: out[b] = sum_g goodloc * lgamma(x + 1) -- a function of the data only.
@@ -1660,8 +1732,7 @@ static int recon_nb_run(const void* logits_any, int l_dtype, int64_t ldl, const 
         C2_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
-                       ngroups, G, part2, db_in_kernel ? part_db : (const float*)nullptr);
+    launch_dtheta_stage1(part_dt, part_flag, ngroups, G, part2, db_in_kernel ? part_db : (const float*)nullptr, st);
     if (dbias && !db_in_kernel) {
         const dim3 grid((unsigned)((G + 255) / 256), kDthSlices);
         if (dl_dtype == C2_BF16)
@@ -1669,7 +1740,7 @@ static int recon_nb_run(const void* logits_any, int l_dtype, int64_t ldl, const 
         else
             hipLaunchKernelGGL(nb_colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)dlogits, lddl, B, G, part2);
     }
-    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta, dbias);
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, part2, G, C, dtheta, dbias);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
     return 0;
@@ -1771,9 +1842,8 @@ static int recon_zinb_run(const float* logits, int64_t ldl, const float* pi, int
     }
     }
     float* part2 = part_loss + ngroups + 32;
-    hipLaunchKernelGGL(nb_dtheta_stage1, dim3((unsigned)((G + 255) / 256), kDthSlices), dim3(256), 0, st, part_dt, part_flag,
-                       ngroups, G, part2, (const float*)nullptr);
-    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, part2, G, C, dtheta,
+    launch_dtheta_stage1(part_dt, part_flag, ngroups, G, part2, (const float*)nullptr, st);
+    hipLaunchKernelGGL(nb_dtheta_stage2, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, part2, G, C, dtheta,
                        (float*)nullptr);
     launch_finalize_sum(part_loss, ngroups, loss_out, st);
     C2_LAUNCH_CHECK();
