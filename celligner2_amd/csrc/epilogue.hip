@@ -988,9 +988,26 @@ __global__ __launch_bounds__(256) void finalize_combine_kernel(PendingSums p, fl
                                                                float w3, float* __restrict__ out, double* __restrict__ accum) {
     __shared__ float red[32];
     float slot[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.count; ++k) {
+    // The first two elements a thread adds of EVERY pending sum are requested before the first sum is formed (elements past
+    // a sum's end re-read its element 0 and are not added): the sums are a few hundred partials each, so this block is a
+    // chain of latencies, and one trip to memory per sum was most of it.  Same additions in the same order.
+    float v0[kMaxPendingSums], v1[kMaxPendingSums];
+#pragma unroll
+    for (int k = 0; k < kMaxPendingSums; ++k) {
+        const bool live = k < p.count && p.n[k] > 0;  // (uniform)
+        const float* src = live ? p.partials[k] : l;   // (no sum in this slot: the loss vector's first element, dropped)
+        const int n = live ? p.n[k] : 0;
+        v0[k] = src[(int)threadIdx.x < n ? threadIdx.x : 0];
+        v1[k] = src[(int)threadIdx.x + 256 < n ? threadIdx.x + 256 : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kMaxPendingSums; ++k) {
+        if (k >= p.count) break;
         float s = 0.f;
-        for (int i = threadIdx.x; i < p.n[k]; i += 256) s += p.partials[k][i];
+        if ((int)threadIdx.x < p.n[k]) s += v0[k];
+        if ((int)threadIdx.x + 256 < p.n[k]) s += v1[k];
+        for (int i = threadIdx.x + 512; i < p.n[k]; i += 256) s += p.partials[k][i];
         s = block_sum<256>(s, red);
         const ptrdiff_t d = p.out[k] - l;
         if (d >= 0 && d < 4) {
