@@ -193,15 +193,6 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
     if (tid == 0) { s_bad = 0; s_nparts = 0; }
     __syncthreads();
     int bad = 0;
-    auto make_key = [&](int64_t r) {
-        int k = 0;
-        for (int j = 0; j < C; ++j) {
-            const int64_t v = cond[r * C + j];
-            bad |= (v != 0 && v != 1);
-            k = (k << 1) | (int)(v == 1);  // column 0 most significant: numeric order == lexicographic row order
-        }
-        return k;
-    };
     auto count_key = [&](int k) {  // one LDS atomic per wave and key present in it (leader = lowest lane holding the key)
         unsigned long long todo = __ballot(k >= 0);
         while (todo) {
@@ -217,11 +208,25 @@ __global__ __launch_bounds__(1024) void partition_small_kernel(const int64_t* __
     // walk over `cond` where part_id is written --, and the weight table is written by 4096 entries in parallel below.
     constexpr int KR = 4;
     auto keys_of = [&](int64_t r0, int (&k)[KR]) {  // rows r0 + q * 1024 + tid, q < KR
+        // (six columns whatever C is -- the spare ones re-read the last -- so that the walk over the columns has no trip
+        // count the compiler does not know: with one it waits for each load where it is issued)
+        int64_t v[KR][6];
 #pragma unroll
         for (int q = 0; q < KR; ++q) {
-            const int64_t r = r0 + (int64_t)q * 1024 + tid;
-            const int key = make_key(min(r, B - 1));
-            k[q] = r < B ? key : -1;
+            const int64_t r = min(r0 + (int64_t)q * 1024 + tid, B - 1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[q][j] = cond[r * C + min(j, C - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            int key = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < C) {
+                    bad |= (v[q][j] != 0 && v[q][j] != 1);
+                    key = (key << 1) | (int)(v[q][j] == 1);
+                }
+            k[q] = (r0 + (int64_t)q * 1024 + tid < B) ? key : -1;
         }
     };
     int kreg[KR];
@@ -584,7 +589,15 @@ __global__ __launch_bounds__(64 * FW, 2) void mmd_fast_kernel(const float* __res
     __shared__ int ldsPj[2][TS];
     __shared__ float ldsWt[MAXP * MAXP];  // the pair-weight table (16 KB): no global load inside the sweep
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < MAXP * MAXP; i += 64 * FW) ldsWt[i] = wt[i];
+    {  // (the table's sixteen loads of a thread together, then the sixteen LDS stores: as a load - store loop each trip
+       // waited for its own load, eight round trips to L2 at the head of every block)
+        float wv[MAXP * MAXP / (64 * FW)];
+#pragma unroll
+        for (int u = 0; u < MAXP * MAXP / (64 * FW); ++u) wv[u] = wt[tid + 64 * FW * u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < MAXP * MAXP / (64 * FW); ++u) ldsWt[tid + 64 * FW * u] = wv[u];
+    }
     const int hi = lane >> 5, lo = lane & 31;
     const int it = blockIdx.x * FW + wave, js = blockIdx.y;
     const int64_t i0 = (int64_t)it * TS;
