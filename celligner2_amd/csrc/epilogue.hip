@@ -778,11 +778,18 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const int64_t r = blockIdx.x;
     const int64_t src = idx[r];
     const int part = blockIdx.y, nparts = gridDim.y;
-    if (idx32_out && threadIdx.x == 0 && part == 0) {
-        idx32_out[r] = (int32_t)src;
-        if (r == n - 1)
-            for (int64_t q = n; q < n_pad; ++q) idx32_out[q] = (int32_t)src;  // padding: any valid row
-    }
+    // The row's scalars (size factor, likelihood constant, condition and class rows) are REQUESTED here, ahead of the
+    // row's columns, and stored at the end with the 32-bit index: as load - store pairs one after the other they were
+    // three dependent trips to random rows in HBM and two store round trips in between (stores count in vmcnt), which
+    // is all this kernel does when the consumers read the resident rows themselves.  A pointer that is absent reads
+    // element 0 of `idx` instead (any valid address), and the value is dropped.
+    const bool lead = part == 0;
+    const bool t0 = threadIdx.x == 0;
+    const int tj = (int)threadIdx.x;
+    const float sfv = (sizefactor ? sizefactor : reinterpret_cast<const float*>(idx))[(lead && t0 && sizefactor) ? src : 0];
+    const float rcv = (rowconst ? rowconst : reinterpret_cast<const float*>(idx))[(lead && t0 && rowconst) ? src : 0];
+    const int64_t cdv = (cond ? cond : idx)[(lead && cond && tj < C) ? src * C + tj : 0];
+    const int64_t clv = (classes ? classes : idx)[(lead && classes && tj < P) ? src * P + tj : 0];
     const float* xs = X + src * ldX;
     float* xd = x_out ? x_out + r * ldxo : nullptr;
     const bool copy_good = goodloc && goodloc_out;
@@ -896,12 +903,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
         }
     }
     if (part != 0) return;
-    if (threadIdx.x == 0 && sizefactor) sf_out[r] = sizefactor[src];
-    if (threadIdx.x == 0 && rowconst) rowconst_out[r] = rowconst[src];
-    if (cond)
-        for (int j = threadIdx.x; j < C; j += 256) cond_out[r * C + j] = cond[src * C + j];
+    if (t0 && sizefactor) sf_out[r] = sfv;
+    if (t0 && rowconst) rowconst_out[r] = rcv;
+    if (cond && tj < C) cond_out[r * C + tj] = cdv;
+    if (classes && tj < P) classes_out[r * P + tj] = clv;
+    if (idx32_out && t0) {
+        idx32_out[r] = (int32_t)src;
+        if (r == n - 1)
+            for (int64_t q = n; q < n_pad; ++q) idx32_out[q] = (int32_t)src;  // padding: any valid row
+    }
+    if (cond)  // (more than 256 condition / class columns: the rest the plain way)
+        for (int j = tj + 256; j < C; j += 256) cond_out[r * C + j] = cond[src * C + j];
     if (classes)
-        for (int j = threadIdx.x; j < P; j += 256) classes_out[r * P + j] = classes[src * P + j];
+        for (int j = tj + 256; j < P; j += 256) classes_out[r * P + j] = classes[src * P + j];
 }
 
 // Dropout keep-masks for every layer of a step in one launch: Philox-4x32-10 keyed by (seed, offset), 16 mask
