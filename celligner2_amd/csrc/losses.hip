@@ -1017,7 +1017,9 @@ __global__ __launch_bounds__(256) void nb_dtheta_direct(const float* __restrict_
     __syncthreads();
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (g < G) {
-#pragma unroll 4
+        // (sixteen groups = up to 48 loads per trip to memory, then sixteen rows of dlogits: with four and eight the walk over
+        // 128 workgroup partials and 128 rows was twelve dependent trips)
+#pragma unroll 16
         for (int grp = ry; grp < ngroups; grp += 4) {
             float v[3];
 #pragma unroll
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(256) void nb_dtheta_direct(const float* __restrict_
             for (int p = 0; p < 3; ++p) s[p] += v[p];
         }
         if (db && d) {
-#pragma unroll 8
+#pragma unroll 16
             for (int64_t b = ry; b < B; b += 4) s[3] += ld_as_f32(d + b * ld + g);
         }
     }
