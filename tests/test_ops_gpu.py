@@ -703,6 +703,18 @@ def test_prep_and_gather():
         ops.gather_rows(T(Xs), None, T(sf), T(cond), None, T(idx), None, None, so2, co, None, xin2, True)
         assert rel(xin2, np.log(1 + Xs[idx].astype(np.float64))) < (1e-6 if dt == torch.float32 else 1e-2)
         assert np.array_equal(so2.cpu().numpy(), sf[idx])
+    # more than 256 condition / class columns: the first 256 of a row travel with its other scalars, the rest in a loop
+    C2, P2 = 300, 700
+    cond2 = rng.integers(0, 2, (N, C2)).astype(np.int64)
+    cls2 = rng.integers(-1, 2, (N, P2)).astype(np.int64)
+    co2 = torch.empty(21, C2, device=DEV, dtype=torch.int64)
+    po2 = torch.empty(21, P2, device=DEV, dtype=torch.int64)
+    so3 = torch.empty(21, device=DEV)
+    i32 = torch.empty(24, device=DEV, dtype=torch.int32)
+    ops.gather_rows(T(X), None, T(sf), T(cond2), T(cls2), T(idx), None, None, so3, co2, po2, None, True, idx32_out=i32)
+    assert np.array_equal(co2.cpu().numpy(), cond2[idx]) and np.array_equal(po2.cpu().numpy(), cls2[idx])
+    assert np.array_equal(so3.cpu().numpy(), sf[idx])
+    assert np.array_equal(i32.cpu().numpy(), np.concatenate([idx, np.repeat(idx[-1:], 3)]).astype(np.int32))
     out = torch.empty(N, G, device=DEV)
     ops.prep_input(T(X), out, True)
     assert rel(out, np.log(1 + X.astype(np.float64))) < 1e-6
