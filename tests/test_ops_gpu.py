@@ -720,6 +720,51 @@ def test_prep_and_gather():
     assert rel(out, np.log(1 + X.astype(np.float64))) < 1e-6
 
 
+def test_deferred_loss_sums_equal_their_own_launches():
+    """c2_defer_loss_sums: the loss entry points leave their second-stage sums to the next combine launch, which forms each
+    of them as the entry point's own launch would (same strides, same tree) -- bit-identical losses, for sums of fewer
+    partials than the combining block has threads, of more than twice as many (the part it walks in a loop), for a sum
+    addressed to the loss vector and for one addressed elsewhere."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+
+    def case(B, D, C):
+        f = T(rng.standard_normal((B, D)).astype(np.float32))
+        cond = np.zeros((B, C), np.int64)
+        lab = rng.integers(0, C, B)
+        lab[:C] = np.arange(C)
+        cond[np.arange(B), lab] = 1
+        part = torch.empty(B, device=DEV, dtype=torch.int32)
+        wt = torch.empty(64 * 64, device=DEV)
+        ops.partition(T(cond), C, None, None, part, wt,
+                      torch.empty(int(ops.lib.c2_partition_ws(B)), device=DEV, dtype=torch.uint8),
+                      torch.zeros(1, device=DEV, dtype=torch.int32))
+        return dict(f=f, part=part, wt=wt, B=B, df=torch.empty(B, D, device=DEV),
+                    ws=torch.empty(ops.mmd_ws(B, B, D), device=DEV))
+
+    cases = [case(40, 8, 2), case(900, 16, 3), case(4500, 64, 3), case(2100, 32, 4)]
+
+    def run(l4, ext):
+        for c, out in zip(cases, (l4[0:1], l4[1:2], l4[2:3], ext)):
+            ops.mmd(c["f"], c["part"], c["wt"], 0, c["B"], 1.5, out, c["df"], c["ws"])
+
+    w = (1.0, 0.25, 3.0, 0.5)
+    ref4, ref_ext, ref6 = torch.zeros(4, device=DEV), torch.zeros(1, device=DEV), torch.empty(6, device=DEV)
+    run(ref4, ref_ext)
+    ops.combine_losses(ref4, w, ref6)
+    l4, ext, out6 = torch.zeros(4, device=DEV), torch.zeros(1, device=DEV), torch.empty(6, device=DEV)
+    ops.defer_loss_sums(True)
+    try:
+        run(l4, ext)
+        ops.combine_losses(l4, w, out6)
+    finally:
+        ops.defer_loss_sums(False)
+        ops.drop_pending_sums()
+    torch.cuda.synchronize()
+    assert torch.equal(l4, ref4) and torch.equal(ext, ref_ext) and torch.equal(out6, ref6)
+    assert all(v != 0 for v in ref4[:3].tolist()) and ref_ext.item() != 0
+
+
 def test_dropout_masks_rate_and_determinism():
     ops = _ops()
     n = 1_000_003
