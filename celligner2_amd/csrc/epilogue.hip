@@ -287,6 +287,14 @@ __device__ __forceinline__ f32x4 sel4(bool keep, const f32x4& v) {
 }
 // the row's sums over the slabs at the EPL chunks (valid columns cc[]): the branch on the slab count OUTSIDE the walk over
 // the chunks, groups of four independent loads per chunk, slabs past the end re-read slab 0 and are zeroed
+#ifndef C2_TAIL_NT
+#define C2_TAIL_NT 1
+#endif
+#if C2_TAIL_NT
+#define C2_TAIL_LD(p) __builtin_nontemporal_load(p)  /* the GEMM's slabs are read once, here */
+#else
+#define C2_TAIL_LD(p) (*(p))
+#endif
 template <int EPL>
 __device__ __forceinline__ void slab_sums(f32x4 (&h)[EPL], const float* __restrict__ rowp, const int (&cc)[EPL], int nslab,
                                           int64_t slab_stride) {
@@ -303,7 +311,11 @@ __device__ __forceinline__ void slab_sums(f32x4 (&h)[EPL], const float* __restri
         for (int i = 0; i < EPL; ++i)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                t[i][u] = *reinterpret_cast<const f32x4*>(rowp + cc[i] + (s0 + u < nslab ? s0 + u : 0) * slab_stride);
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(rowp + cc[i] + (s0 + u < nslab ? s0 + u : 0) * slab_stride);
+                if constexpr (EPL == 4) t[i][u] = C2_TAIL_LD(src);  // (rows of 1024: the slabs are tens of MB; narrower layers' slabs
+                else t[i][u] = *src;                                 //  are still in the caches, and the hint measured slower there)
+            }
 #pragma unroll
         for (int i = 0; i < EPL; ++i)
             h[i] += (sel4(s0 < nslab, t[i][0]) + sel4(s0 + 1 < nslab, t[i][1])) +

@@ -20,9 +20,37 @@ def read(d, counter):
     return acc
 
 
+# The step's HBM-bound kernels, for the same two passes: name fragment -> (label, algorithmic bytes per launch at C4 or None).
+# Algorithmic bytes: NB loss 4096 x 19 000 x (2 logits + 2 counts' worth... see DESIGN.md section 5) is quoted there, not here;
+# Adam = 30 bytes per parameter (p, g, m, v read; p, m, v and one 2-byte operand copy written).
+OTHERS = [("nb_rowreg_kernel", "NB loss"), ("adam_dev_kernel", "fused Adam"), ("mmd_fast_kernel", "MMD"),
+          ("epilogue_fwd_vec_kernel<float, 4>", "encoder L0 tail, forward"),
+          ("epilogue_bwd_vec_kernel<float, 4>", "encoder L0 tail, backward"),
+          ("nb_dtheta_stage1", "dispersion / bias partial reduction, stage 1"), ("gemv_bias_kernel", "W c GEMV")]
+
+
+def read_others(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            for frag, label in OTHERS:
+                if frag in r["Kernel_Name"]:
+                    acc[label].append(float(r["Counter_Value"]))
+    return acc
+
+
 def main():
     out, steps = sys.argv[1], int(sys.argv[2])
     fe, wr = read(os.path.join(out, "fetch"), "FETCH_SIZE"), read(os.path.join(out, "write"), "WRITE_SIZE")
+    ofe, owr = read_others(os.path.join(out, "fetch"), "FETCH_SIZE"), read_others(os.path.join(out, "write"), "WRITE_SIZE")
+    others = {}
+    for label in ofe:
+        f_kb = sum(ofe[label]) / len(ofe[label])
+        w_kb = sum(owr[label]) / max(len(owr[label]), 1)
+        others[label] = dict(launches_per_step=len(ofe[label]) / steps, fetch_kb=f_kb, write_kb=w_kb,
+                             hbm_bytes_per_launch=f_kb * 1024 * 2 + w_kb * 1024)
     shapes, total, launches = {}, 0.0, 0.0
     for k in sorted(fe):
         f_kb = sum(fe[k]) / len(fe[k])
@@ -42,7 +70,9 @@ def main():
                 "read the batch in place from the resident matrix)",
         "steps_profiled": steps, "shapes": shapes, "hbm_bytes_per_step": total,
         "algorithmic_bytes_per_step": algorithmic, "launches_per_step": launches,
-        "traffic_bytes_per_launch": total / max(launches, 1e-9)}, indent=1))
+        "traffic_bytes_per_launch": total / max(launches, 1e-9),
+        "other_kernels_note": "the step's HBM-bound kernels in the same two passes (same correction); not part of any field above",
+        "other_kernels": others}, indent=1))
 
 
 if __name__ == "__main__":
