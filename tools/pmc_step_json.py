@@ -20,10 +20,10 @@ def read(d, counter):
     return acc
 
 
-# The step's HBM-bound kernels, for the same two passes: name fragment -> (label, algorithmic bytes per launch at C4 or None).
-# Algorithmic bytes: NB loss 4096 x 19 000 x (2 logits + 2 counts' worth... see DESIGN.md section 5) is quoted there, not here;
-# Adam = 30 bytes per parameter (p, g, m, v read; p, m, v and one 2-byte operand copy written).
-OTHERS = [("nb_rowreg_kernel", "NB loss"), ("adam_dev_kernel", "fused Adam"), ("mmd_fast_kernel", "MMD"),
+# The step's HBM-bound kernels in the same two passes: (kernel-name fragment, label).  Their algorithmic bytes are quoted in
+# DESIGN.md section 5 beside these measurements.
+OTHERS = [("nb_rowreg_kernel", "NB loss"), ("adam_dev_kernel", "fused Adam"), ("adam_kernel", "fused Adam"),
+          ("mmd_fast_kernel", "MMD"),
           ("epilogue_fwd_vec_kernel<float, 4>", "encoder L0 tail, forward"),
           ("epilogue_bwd_vec_kernel<float, 4>", "encoder L0 tail, backward"),
           ("nb_dtheta_stage1", "dispersion / bias partial reduction, stage 1"), ("gemv_bias_kernel", "W c GEMV")]
