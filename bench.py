@@ -349,7 +349,7 @@ def main():
         prof_host.disable()
         pstats.Stats(prof_host, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     prof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
-    losses_seen = [float(trainer.current_loss)]
+    losses_seen = [float(trainer.current_loss.detach())]
     trace("timed steps done")
     model._engine().check_status()
     dt, cells = over_ranks(dt, rows)
